@@ -1,0 +1,192 @@
+"""Headline benchmark: LiDAR scans/sec of the LiDOG training step (MinkUNet34 + BEV head) on synthetic
+120k-point / 0.05 m scans (BASELINE.json configs[1], batch 4 per GPU), one process per GPU over RCCL.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward (is_train=True, BEV head included) + both DICE losses + backward + gradient
+all-reduce + Adam update; inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # vector fp32 peak (the sparse stack uses vector FMA, not MFMA)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="scans per GPU (configs[1]: bs=4)")
+    ap.add_argument("--config", default="kitti120k")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP events around every launch of the dominant kernel (the gathered GEMM of csrc/sconv.hip), on the
+    stream it is launched on, with its algorithmic bytes/FLOPs."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def wrap(self, me):
+        orig = me._gemm
+        timer = self
+
+        def timed(A, gather, B, bias, m, Cin, Cout, out, scatter):
+            if not timer.enabled:
+                return orig(A, gather, B, bias, m, Cin, Cout, out, scatter)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(A, gather, B, bias, m, Cin, Cout, out, scatter)
+            e1.record()
+            rows = m.P
+            # algorithmic traffic of one launch: every distinct input row and weight read once, every
+            # product row written once, the gather index read once (SURVEY.md 8(d) per-layer formula)
+            n_src = A.shape[0]
+            bytes_ = 4 * (min(n_src, rows) * Cin + rows * Cout + m.K * Cin * Cout) + 4 * rows
+            timer.records.append((e0, e1, bytes_, 2.0 * rows * Cin * Cout))
+        me._gemm = timed
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+        by = sum(r[2] for r in self.records)
+        fl = sum(r[3] for r in self.records)
+        return dict(launches=len(self.records), total_ms=ms, bytes=by, flops=fl)
+
+
+def cpu_baseline(config, steps_budget_s=30.0):
+    """The CPU oracle (ME-equivalent restatement, per-offset gather -> BLAS GEMM -> scatter-add) timed on
+    this box's host cores on ONE scan of the same workload, full training step."""
+    import oracle.me_cpu as OME
+    from oracle.ref_torch import Encoder2DRef, sparse2super_ref, soft_dice_loss_ref, dice_loss_ref
+    from lidog_amd.minkunet import make_models
+    from lidog_amd import synth
+    OME.set_mode("blas")
+    torch.manual_seed(0)
+    cls = make_models(OME, Encoder2DRef, lambda x, bound, voxel, pool: sparse2super_ref(x.C, x.F, bound, voxel, pool))
+    model = cls.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"],
+                              mapping_bound_2d=50.0)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    b = synth.make_batch([0], config, device="cpu")
+    t0 = time.time()
+    n = 0
+    while True:
+        st = OME.SparseTensor(coordinates=b["coords_int"], features=b["source_features0"])
+        sem, bev = model(st, is_train=True)
+        loss = 0.5 * soft_dice_loss_ref(sem.F, b["source_sem_labels0"]) + \
+            0.5 * dice_loss_ref(bev["block8"].view(-1, 7), b["source_bev_labels0"]["block8"].view(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        n += 1
+        if time.time() - t0 > steps_budget_s or n >= 3:
+            break
+    dt = time.time() - t0
+    OME.set_mode("exact")
+    return {"value": n / dt, "unit": "scans/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training step(s) of 1 synthetic {config} scan, MinkUNet34BEV B=50, oracle blas mode "
+                      f"(per-offset gather->GEMM->scatter-add), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    from lidog_amd.trainer import FlatAdam, LiDOGStep, setup_data_parallel
+
+    timer = GemmTimer()
+    if not args.no_kernel_timing:
+        timer.wrap(ME)
+
+    torch.manual_seed(1234)  # pipeline.seed of configs/lidog/single/semantickitti.yaml
+    model = lidog_amd.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5,
+                                    decoder_2d_level=["block8"], mapping_bound_2d=50.0).cuda()
+    model = setup_data_parallel(model)
+    model.train()
+    step = LiDOGStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4), source_weights=(0.5, 0.5))
+
+    # two distinct batches per rank, resident in HBM, cycled (scan seeds differ per rank)
+    base = rank * 2 * args.batch
+    batches = [synth.make_batch(range(base + i * args.batch, base + (i + 1) * args.batch), args.config, "cuda")
+               for i in range(2)]
+    n_vox = sum(b["coords_int"].shape[0] for b in batches) / (2 * args.batch)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step.training_step(batches[i % 2])
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step.training_step(batches[i % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    loss = float(out["loss"])
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        res = {"metric": "LiDAR scans/sec, MinkUNet34+BEV training step @120k pts", "value": value, "unit": "scans/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"train_lidog.py Synth4D-kitti-like MinkUNet34 + BEV head (B=50 m, 0.05 m voxels), "
+                                      f"bs={args.batch}/GPU, {args.config} synthetic scans, "
+                                      f"{n_vox:.0f} voxels/scan, SoftDICE+DICE, Adam", "global_batch": world * args.batch,
+                          "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+               "loss": loss}
+        s = timer.summary()
+        if s:
+            gbs = s["bytes"] / (s["total_ms"] * 1e-3) / 1e9
+            tfl = s["flops"] / (s["total_ms"] * 1e-3) / 1e12
+            res["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "k_sconv_gemm (gathered GEMM)",
+                               "avg_launch_us": 1e3 * s["total_ms"] / s["launches"], "launches": s["launches"],
+                               "share_of_step": s["total_ms"] / (1e3 * dt),
+                               "fp32_tflops": tfl, "fp32_peak_tflops": FP32_PEAK_TFLOPS,
+                               "fp32_frac": tfl / FP32_PEAK_TFLOPS}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.config)
+            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * lidog_amd.h -- C ABI of the MI355X-native sparse-voxel engine (liblidog_amd.so).
+ *
+ * This is the drop-in boundary for LiDOG's hot path.  The reference reaches
+ * this functionality through the python package MinkowskiEngine 0.5.4 and
+ * torch.nn; each entry point below cites the reference call site it replaces
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *   - the caller owns all memory; the library never allocates or frees
+ *     caller-visible buffers and keeps no state between calls;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it
+ *     unless documented as synchronising;
+ *   - return value 0 = success, non-zero = failure with a message in
+ *     lidog_last_error() (thread-local);
+ *   - coordinates are int32 rows (batch, x, y, z); features are float32
+ *     row-major [rows, channels]; all index tables are int32.
+ *   - coordinate components must lie in [-65536, 65535], batch in [0, 4095]
+ *     (63-bit packed hash key); violations set *err_flag (device int32) to 1.
+ */
+#ifndef LIDOG_AMD_H
+#define LIDOG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *lidog_last_error(void);
+int lidog_abi_version(void);
+
+/* ------------------------------------------------------------------ coordinate maps
+ * Replaces MinkowskiEngine's CoordinateManager (insert_and_map / stride / kernel map),
+ * reached from ME.SparseTensor(...) at utils/pipelines/trainer_lighting_2d.py:151 and
+ * implicitly from every ME.MinkowskiConvolution call in utils/models/minkunet_bev.py:307-371. */
+
+/* slots needed for n rows (power of two, load factor <= 0.5) */
+int64_t lidog_hash_capacity(int64_t n);
+
+/* Build the hash table of a coordinate map: keys[cap] (uint64), vals[cap] (int32 row of the FIRST
+ * occurrence of that coordinate).  first_row[i] = vals of row i's key (== i for unique input).
+ * n_unique_dev receives the number of distinct coordinates (device int64). */
+int lidog_coords_insert(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int64_t cap,
+                        int32_t *first_row, int64_t *n_unique_dev, int32_t *err_flag, void *stream);
+
+/* Compact a map with duplicates: unique_rows[j] = first-occurrence row of output row j (ascending),
+ * inverse[i] = output row of input row i; rewrites vals to output rows.  scan_ws: int32[n + 2048]. */
+int lidog_coords_compact(const int32_t *first_row, int64_t n, const uint64_t *keys, int32_t *vals, int64_t cap,
+                         const int32_t *coords, int32_t *unique_rows, int32_t *inverse, int32_t *scan_ws,
+                         void *stream);
+
+/* Strided map (conv kernel 2 stride 2, minkunet_bev.py:62,69,76,83): out coordinate =
+ * floor(c / new_stride) * new_stride per spatial dim, duplicates collapsed, rows in first-occurrence
+ * order of the parent.  coords_out has room for n_in rows; n_out_dev (device int64) gets the count.
+ * parent2child[i] = output row of parent row i.  ws: int32[2 * n_in + 2048]. */
+int lidog_coords_stride(const int32_t *coords_in, int64_t n_in, int32_t new_stride, uint64_t *keys,
+                        int32_t *vals, int64_t cap, int32_t *parent2child, int32_t *coords_out,
+                        int64_t *n_out_dev, int32_t *ws, int32_t *err_flag, void *stream);
+
+/* Kernel map, neighbour-table form, k-major: nbr[k * n_out + o] = row of the input map holding
+ * coordinate out[o] + offsets[k], or -1.  offsets_host is a HOST array [K,3] (x,y,z), K <= 125. */
+int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const uint64_t *in_keys, const int32_t *in_vals,
+                     int64_t in_cap, const int32_t *offsets_host, int32_t K, int32_t *nbr, void *stream);
+
+/* Rule book from the neighbour table (wavefront ballot + prefix-sum compaction): for each k the pairs
+ * (pair_in, pair_out) in ascending out-row order, k_off_dev[K+1] segment offsets (device int64),
+ * pos_out[k*n_out+o] = pair position or -1, pos_in[k*n_in+i] = pair position or -1.
+ * pair_* need room for n_out*K entries unless the caller knows P.  ws: int32[(blocks+1)*K + K + 2],
+ * blocks = ceil(n_out / 1024). */
+int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t K, int64_t *k_off_dev,
+                           int32_t *pair_in, int32_t *pair_out, int32_t *pos_out, int32_t *pos_in, int32_t *ws,
+                           void *stream);
+
+/* ------------------------------------------------------------------ sparse convolution
+ * Replaces ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward and backward
+ * (minkunet_bev.py:57-123 construction, :307-371 calls; kernel layout [K,Cin,Cout], :404). */
+
+/* Gathered GEMM over the rule book: for every tile t (tile_k[t], tile_row0[t], tile_rows[t] <= 128)
+ *   T[dst(p)][:] = A[gather[p]][:] . B[tile_k]      p = tile_row0 .. tile_row0 + tile_rows
+ * B is [K, Cin, Cout] row-major.  dst(p) = p when scatter == NULL, else scatter[p] (each destination
+ * written once).  The product of one row is an fmaf chain over ci ascending starting from 0
+ * (bit-identical to oracle/me_oracle.c:orc_conv_fwd before its scatter-add).
+ * bias (may be NULL) [Cout] is added after the chain. */
+int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
+                     const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles,
+                     int32_t Cin, int32_t Cout, float *T, const int32_t *scatter, void *stream);
+
+/* out[o][:] = sum over k ascending of T[pos[k*n + o]][:] (skipping -1), plus bias if not NULL.
+ * The gather->GEMM->scatter-add order of the ME CPU algorithm, without atomics. */
+int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
+                       float *out, void *stream);
+
+/* gW[k] = sum over pairs p of segment k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
+ * partial: float[n_split * K * Cin * Cout] workspace; the split partials are summed in split order. */
+int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
+                      const int64_t *k_off_dev, int32_t K, int32_t Cin, int32_t Cout, int32_t n_split,
+                      float *partial, float *gW, void *stream);
+
+/* Wt[k][co][ci] = W[k][ci][co] */
+int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout, float *Wt, void *stream);
+
+/* ------------------------------------------------------------------ BatchNorm / ReLU on COO features
+ * Replaces ME.MinkowskiBatchNorm (nn.BatchNorm1d over all rows, minkunet_bev.py:60,406-408) and
+ * ME.MinkowskiReLU (:124).  layout: x[n, C] when hw == 1; NCHW with hw = H*W otherwise
+ * (nn.BatchNorm2d of utils/models/conv2d.py:18,21). */
+
+/* per-channel sums in double: sums[2*C] = (sum x, sum x^2); accumulates into sums (zero it first) */
+int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, void *stream);
+/* mean/invstd from sums and count; updates running stats (momentum, unbiased var) when not NULL */
+int lidog_bn_finalize(const double *sums, double count, int32_t C, float eps, float momentum, float *mean,
+                      float *invstd, float *running_mean, float *running_var, void *stream);
+/* y = (x - mean) * invstd * w + b (+ residual) (relu).  In-place (y == x) allowed. */
+int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean, const float *invstd,
+                   const float *w, const float *b, const float *residual, int32_t relu, float *y, void *stream);
+/* backward reduce: sums[2*C] += (sum dy', sum dy'*xhat) with dy' = dy * (y > 0) when relu_y != NULL */
+int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
+                        const float *mean, const float *invstd, double *sums, void *stream);
+/* dx = w*invstd*(dy' - s0/count - xhat*s1/count); dres = dy' when dres != NULL; dw = s1, db = s0 */
+int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
+                       const float *mean, const float *invstd, const float *w, const double *sums, double count,
+                       float *dx, float *dres, float *dw, float *db, void *stream);
+int lidog_relu_fwd(const float *x, int64_t n, float *y, void *stream);
+int lidog_relu_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream);
+int lidog_add(const float *a, const float *b, int64_t n, float *out, void *stream);
+
+/* ------------------------------------------------------------------ BEV projection
+ * Replaces MinkUNetBaseBEV.sparse2super (minkunet_bev.py:158-230) without materialising the
+ * [H,W,C] tensor: a [B,H,W] int32 winner map (last row wins) + fused view-scramble + MaxPool2d. */
+int lidog_bev_winner(const int32_t *coords, int64_t n, const int32_t *lut_x, const int32_t *lut_y, int32_t lut_lo,
+                     int32_t lut_n, int32_t H, int32_t W, int32_t *winner /*[B,H,W], pre-filled -1*/,
+                     int32_t *pixel /*[n] linear b*H*W+py*W+px or -1*/, void *stream);
+int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, int32_t B, int32_t H, int32_t W,
+                       int32_t pk, int32_t ps, int32_t pp, int32_t Ho, int32_t Wo, float *out /*[B,C,Ho,Wo]*/,
+                       int32_t *argsrc /*[B,C,Ho,Wo] row*C+c of the arg-max cell or -1*/, void *stream);
+int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems, const int32_t *winner,
+                       const int32_t *pixel, int64_t n, int32_t C, float *gcell /*[n,C] zeroed scratch*/,
+                       float *gfeats /*[n,C]*/, void *stream);
+
+/* ------------------------------------------------------------------ dense 2-D BEV head (MFMA)
+ * Replaces nn.Conv2d(k3,s2,p1,bias=False) x2 and nn.Conv2d(k1) of Encoder2D
+ * (utils/models/conv2d.py:16-22,116,184-185).  NCHW float32, exact-f32 MFMA. */
+int lidog_conv2d_fwd(const float *x, const float *w, const float *bias, int32_t B, int32_t Cin, int32_t H,
+                     int32_t W, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *y, void *stream);
+/* ws: 9*Cin*Cout floats (parity-class repacked weights) for k3 s2 p1; unused for k1 */
+int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                       int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *gx, float *ws,
+                       void *stream);
+int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                       int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *gw, float *gbias,
+                       float *ws, int64_t ws_floats, void *stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * Replaces torch.optim.Adam(lr, weight_decay) of trainer_lighting_2d.py:356-358 on a flat buffer. */
+int lidog_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDOG_AMD_H */

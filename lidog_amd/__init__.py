@@ -1,0 +1,15 @@
+"""lidog_amd -- MI355X-native engine for LiDOG's hot path (MinkUNet34 + BEV head).
+
+Public surface:
+  lidog_amd.me            MinkowskiEngine-compatible operator API (HIP kernels via the C ABI)
+  lidog_amd.bev           sparse2super + Encoder2D (fused BEV projection, MFMA 2-D head)
+  lidog_amd.MinkUNet34 / MinkUNet34BEV    the reference models wired to those operators
+  lidog_amd.losses        SoftDICELoss / DICELoss on the device
+  lidog_amd.trainer       training step, Adam, RCCL data parallelism
+"""
+from . import me, bev, losses  # noqa: F401
+from .minkunet import make_models
+
+_models = make_models(me, bev.Encoder2D, bev.sparse2super)
+MinkUNet34 = _models.MinkUNet34
+MinkUNet34BEV = _models.MinkUNet34BEV

@@ -1,0 +1,88 @@
+"""ctypes binding of liblidog_amd.so (the C ABI declared in include/lidog_amd.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "_C", "liblidog_amd.so")
+
+_i32, _i64, _p, _f, _d = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_double
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "lidog_abi_version": [],
+    "lidog_hash_capacity": [_i64],
+    "lidog_coords_insert": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p],
+    "lidog_coords_compact": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p],
+    "lidog_coords_stride": [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p],
+    "lidog_kernel_map": [_p, _i64, _p, _p, _i64, _p, _i32, _p, _p],
+    "lidog_kernel_map_pairs": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
+    "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_transpose_kernel": [_p, _i32, _i32, _i32, _p, _p],
+    "lidog_bn_stats": [_p, _i64, _i32, _i64, _p, _p],
+    "lidog_bn_finalize": [_p, _d, _i32, _f, _f, _p, _p, _p, _p, _p],
+    "lidog_bn_apply": [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
+    "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p],
+    "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
+    "lidog_relu_fwd": [_p, _i64, _p, _p],
+    "lidog_relu_bwd": [_p, _p, _i64, _p, _p],
+    "lidog_add": [_p, _p, _i64, _p, _p],
+    "lidog_bev_winner": [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_bev_pool_fwd": [_p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_bev_pool_bwd": [_p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p],
+    "lidog_conv2d_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
+    "lidog_conv2d_dgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_conv2d_wgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
+    "lidog_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i32, _f, _p],
+}
+_RESTYPES = {"lidog_hash_capacity": _i64}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -m lidog_amd.build` (hipcc, gfx950). "
+                "lidog_amd has no CPU or torch fallback.")
+        L = ctypes.CDLL(SO_PATH)
+        L.lidog_last_error.restype = ctypes.c_char_p
+        L.lidog_last_error.argtypes = []
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """device pointer of a contiguous tensor (None -> NULL)"""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "lidog_amd kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """call a status-returning entry point on the current torch stream; raise on failure"""
+    L = load()
+    rc = getattr(L, name)(*args, stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.lidog_last_error().decode()}")
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"lidog_amd: {what} must live on the GPU (got {t.device}); there is no CPU path")

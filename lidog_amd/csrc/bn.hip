@@ -1,0 +1,318 @@
+// BatchNorm (training statistics in double, fused affine + residual + ReLU), ReLU and add on
+// COO feature matrices [rows, C] and on NCHW images (hw = H*W).  Reference semantics:
+// nn.BatchNorm1d inside ME.MinkowskiBatchNorm (utils/models/minkunet_bev.py:60,406-408),
+// nn.BatchNorm2d of utils/models/conv2d.py:18,21; eps 1e-5, momentum 0.1, biased variance for
+// normalisation, unbiased for running_var.
+#include "common.h"
+
+// MODE 0: (x, x*x)            -> statistics
+// MODE 1: (dy', dy' * xhat)   -> backward reductions, dy' = dy * (relu_y > 0) when relu_y given
+template <int MODE>
+__device__ __forceinline__ void red_terms(float x, float dy, float ry, bool has_relu, float mean, float invstd,
+                                          double &t0, double &t1) {
+    if (MODE == 0) {
+        t0 += (double)x;
+        t1 += (double)x * (double)x;
+    } else {
+        float g = (has_relu && !(ry > 0.f)) ? 0.f : dy;
+        float xh = (x - mean) * invstd;
+        t0 += (double)g;
+        t1 += (double)g * (double)xh;
+    }
+}
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict__ x, const float4 *__restrict__ dy,
+                                                       const float4 *__restrict__ ry, int64_t n, int C4,
+                                                       const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd, double *__restrict__ sums) {
+    __shared__ double red[256 * 8];
+    const int RB = 256 / C4;
+    const int tid = threadIdx.x;
+    const int r = tid / C4, c4 = tid % C4;
+    const bool active = r < RB;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float m[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+    if (MODE == 1 && active) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = mean[c4 * 4 + j]; is[j] = invstd[c4 * 4 + j]; }
+    }
+    if (active) {
+        for (int64_t row = (int64_t)blockIdx.x * RB + r; row < n; row += (int64_t)gridDim.x * RB) {
+            float4 v = x[row * C4 + c4];
+            float4 g = make_float4(0, 0, 0, 0), y = make_float4(1, 1, 1, 1);
+            if (MODE == 1) {
+                g = dy[row * C4 + c4];
+                if (ry) y = ry[row * C4 + c4];
+            }
+            red_terms<MODE>(v.x, g.x, y.x, ry != nullptr, m[0], is[0], a[0], a[4]);
+            red_terms<MODE>(v.y, g.y, y.y, ry != nullptr, m[1], is[1], a[1], a[5]);
+            red_terms<MODE>(v.z, g.z, y.z, ry != nullptr, m[2], is[2], a[2], a[6]);
+            red_terms<MODE>(v.w, g.w, y.w, ry != nullptr, m[3], is[3], a[3], a[7]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
+    __syncthreads();
+    if (active && r == 0) {
+        const int C = C4 * 4;
+        for (int rr = 1; rr < RB; ++rr)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomic_add_f64(&sums[c4 * 4 + j], a[j]);
+            atomic_add_f64(&sums[C + c4 * 4 + j], a[4 + j]);
+        }
+    }
+}
+
+// generic layout (NCHW planes, or [n,C] with C % 4 != 0 as hw = 1 "planes" of strided access)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_colreduce_plane(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         const float *__restrict__ ry, int64_t hw, int C,
+                                                         const float *__restrict__ mean,
+                                                         const float *__restrict__ invstd,
+                                                         double *__restrict__ sums) {
+    __shared__ double red[2][4];
+    const int64_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const int64_t base = plane * hw;
+    const int64_t chunk = (hw + gridDim.y - 1) / gridDim.y;
+    const int64_t i0 = (int64_t)blockIdx.y * chunk;
+    const int64_t i1 = (i0 + chunk < hw) ? i0 + chunk : hw;
+    double t0 = 0, t1 = 0;
+    float m = 0.f, is = 1.f;
+    if (MODE == 1) { m = mean[c]; is = invstd[c]; }
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+        red_terms<MODE>(x[base + i], MODE ? dy[base + i] : 0.f, (MODE && ry) ? ry[base + i] : 1.f, ry != nullptr, m, is,
+                        t0, t1);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        t0 += __shfl_down(t0, d);
+        t1 += __shfl_down(t1, d);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = t0; red[1][threadIdx.x >> 6] = t1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_add_f64(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomic_add_f64(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// [n, C] with C % 4 != 0: one block per channel, strided rows
+template <int MODE>
+__global__ __launch_bounds__(256) void k_colreduce_strided(const float *__restrict__ x, const float *__restrict__ dy,
+                                                           const float *__restrict__ ry, int64_t n, int C,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd,
+                                                           double *__restrict__ sums) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    double t0 = 0, t1 = 0;
+    float m = 0.f, is = 1.f;
+    if (MODE == 1) { m = mean[c]; is = invstd[c]; }
+    for (int64_t i = threadIdx.x; i < n; i += 256)
+        red_terms<MODE>(x[i * C + c], MODE ? dy[i * C + c] : 0.f, (MODE && ry) ? ry[i * C + c] : 1.f, ry != nullptr, m,
+                        is, t0, t1);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        t0 += __shfl_down(t0, d);
+        t1 += __shfl_down(t1, d);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = t0; red[1][threadIdx.x >> 6] = t1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_add_f64(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomic_add_f64(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+template <int MODE>
+static int launch_colreduce(const float *x, const float *dy, const float *ry, int64_t n, int C, int64_t hw,
+                            const float *mean, const float *invstd, double *sums, hipStream_t st) {
+    if (n == 0) return 0;
+    if (hw == 1) {
+        if (C % 4 == 0 && C / 4 <= 256) {
+            int C4 = C / 4, RB = 256 / C4;
+            int64_t nb = cdiv64(n, (int64_t)RB * 8);
+            if (nb > 2048) nb = 2048;
+            k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy,
+                                                                (const float4 *)ry, n, C4, mean, invstd, sums);
+        } else {
+            k_colreduce_strided<MODE><<<(unsigned)C, 256, 0, st>>>(x, dy, ry, n, C, mean, invstd, sums);
+        }
+    } else {
+        // n = number of images B; planes = B*C
+        int64_t planes = n * C;
+        int chunks = (int)cdiv64(hw, 16384);
+        if (chunks < 1) chunks = 1;
+        if (chunks > 64) chunks = 64;
+        k_colreduce_plane<MODE><<<dim3((unsigned)planes, (unsigned)chunks), 256, 0, st>>>(x, dy, ry, hw, C, mean, invstd,
+                                                                                          sums);
+    }
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, void *stream) {
+    return launch_colreduce<0>(x, nullptr, nullptr, n, C, hw, nullptr, nullptr, sums, (hipStream_t)stream);
+}
+
+extern "C" int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C,
+                                   int64_t hw, const float *mean, const float *invstd, double *sums, void *stream) {
+    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, (hipStream_t)stream);
+}
+
+__global__ void k_bn_finalize(const double *__restrict__ sums, double count, int C, float eps, float momentum,
+                              float *__restrict__ mean, float *__restrict__ invstd, float *running_mean,
+                              float *running_var) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        double unb = (count > 1) ? var * count / (count - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int lidog_bn_finalize(const double *sums, double count, int32_t C, float eps, float momentum, float *mean,
+                                 float *invstd, float *running_mean, float *running_var, void *stream) {
+    k_bn_finalize<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(sums, count, C, eps, momentum, mean, invstd,
+                                                                   running_mean, running_var);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ elementwise passes
+__device__ __forceinline__ int chan_of(int64_t idx, int C, int64_t hw) {
+    return (hw == 1) ? (int)(idx % C) : (int)((idx / hw) % C);
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int64_t total, int C, int64_t hw,
+                                                  const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                  const float *__restrict__ w, const float *__restrict__ b,
+                                                  const float *__restrict__ res, int relu, float *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int c = chan_of(i, C, hw);
+        float v = (x[i] - mean[c]) * invstd[c] * w[c] + b[c];
+        if (res) v += res[i];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply4(const float4 *__restrict__ x, int64_t total4, int C4,
+                                                   const float4 *__restrict__ mean, const float4 *__restrict__ invstd,
+                                                   const float4 *__restrict__ w, const float4 *__restrict__ b,
+                                                   const float4 *__restrict__ res, int relu, float4 *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        float4 v = x[i], m = mean[c4], s = invstd[c4], ww = w[c4], bb = b[c4];
+        v.x = (v.x - m.x) * s.x * ww.x + bb.x;
+        v.y = (v.y - m.y) * s.y * ww.y + bb.y;
+        v.z = (v.z - m.z) * s.z * ww.z + bb.z;
+        v.w = (v.w - m.w) * s.w * ww.w + bb.w;
+        if (res) { float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        y[i] = v;
+    }
+}
+
+static unsigned ew_grid(int64_t n) {
+    int64_t g = cdiv64(n, 256);
+    return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+extern "C" int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean,
+                              const float *invstd, const float *w, const float *b, const float *residual,
+                              int32_t relu, float *y, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int64_t total = n * C * hw;
+    if (total == 0) return 0;
+    if (hw == 1 && C % 4 == 0) {
+        k_bn_apply4<<<ew_grid(total / 4), 256, 0, st>>>((const float4 *)x, total / 4, C / 4, (const float4 *)mean,
+                                                        (const float4 *)invstd, (const float4 *)w, (const float4 *)b,
+                                                        (const float4 *)residual, relu, (float4 *)y);
+    } else {
+        k_bn_apply<<<ew_grid(total), 256, 0, st>>>(x, total, C, hw, mean, invstd, w, b, residual, relu, y);
+    }
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ x,
+                                                      const float *__restrict__ ry, int64_t total, int C, int64_t hw,
+                                                      const float *__restrict__ mean,
+                                                      const float *__restrict__ invstd, const float *__restrict__ w,
+                                                      const double *__restrict__ sums, double inv_count,
+                                                      float *__restrict__ dx, float *__restrict__ dres) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int c = chan_of(i, C, hw);
+        float g = dy[i];
+        if (ry && !(ry[i] > 0.f)) g = 0.f;
+        float is = invstd[c];
+        float xh = (x[i] - mean[c]) * is;
+        float m0 = (float)(sums[c] * inv_count), m1 = (float)(sums[C + c] * inv_count);
+        dx[i] = (g - m0 - xh * m1) * is * w[c];
+        if (dres) dres[i] = g;
+    }
+}
+
+__global__ void k_bn_param_grads(const double *__restrict__ sums, int C, float *dw, float *db) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (db) db[c] = (float)sums[c];
+    if (dw) dw[c] = (float)sums[C + c];
+}
+
+extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C,
+                                  int64_t hw, const float *mean, const float *invstd, const float *w,
+                                  const double *sums, double count, float *dx, float *dres, float *dw, float *db,
+                                  void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int64_t total = n * C * hw;
+    if (total > 0)
+        k_bn_bwd_apply<<<ew_grid(total), 256, 0, st>>>(dy, x, relu_y, total, C, hw, mean, invstd, w, sums, 1.0 / count,
+                                                       dx, dres);
+    k_bn_param_grads<<<(C + 127) / 128, 128, 0, st>>>(sums, C, dw, db);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_relu_fwd(const float *__restrict__ x, int64_t n, float *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = fmaxf(x[i], 0.f);
+}
+__global__ __launch_bounds__(256) void k_relu_bwd(const float *__restrict__ dy, const float *__restrict__ y,
+                                                  int64_t n, float *__restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = (y[i] > 0.f) ? dy[i] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
+                                             float *__restrict__ o) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = a[i] + b[i];
+}
+
+extern "C" int lidog_relu_fwd(const float *x, int64_t n, float *y, void *stream) {
+    if (n) k_relu_fwd<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(x, n, y);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int lidog_relu_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream) {
+    if (n) k_relu_bwd<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(dy, y, n, dx);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int lidog_add(const float *a, const float *b, int64_t n, float *out, void *stream) {
+    if (n) k_add<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(a, b, n, out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}

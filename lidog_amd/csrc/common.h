@@ -1,0 +1,60 @@
+// Shared helpers for liblidog_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lidog_amd.h"
+
+void lidog_set_error(const char *fmt, ...);
+
+#define LIDOG_CHECK_HIP(expr)                                                                   \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            lidog_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+#define LIDOG_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            lidog_set_error(__VA_ARGS__); \
+            return 2;                     \
+        }                                 \
+    } while (0)
+
+#define LIDOG_LAUNCH_CHECK() LIDOG_CHECK_HIP(hipGetLastError())
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 63-bit packed coordinate key: batch 12 bits, x/y/z 17 bits each (biased by 65536).
+#define LIDOG_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint64_t lidog_pack(int b, int x, int y, int z, int *bad) {
+    unsigned ux = (unsigned)(x + 65536), uy = (unsigned)(y + 65536), uz = (unsigned)(z + 65536);
+    if (((unsigned)b > 4095u) | (ux > 131071u) | (uy > 131071u) | (uz > 131071u)) *bad = 1;
+    return ((uint64_t)(unsigned)b << 51) | ((uint64_t)ux << 34) | ((uint64_t)uy << 17) | (uint64_t)uz;
+}
+
+__device__ __forceinline__ uint64_t lidog_mix(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// row of `key` in an open-addressing table, or -1
+__device__ __forceinline__ int lidog_find(const uint64_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                          uint64_t mask, uint64_t key) {
+    uint64_t slot = lidog_mix(key) & mask;
+    for (;;) {
+        uint64_t k = keys[slot];
+        if (k == key) return vals[slot];
+        if (k == LIDOG_EMPTY_KEY) return -1;
+        slot = (slot + 1) & mask;
+    }
+}

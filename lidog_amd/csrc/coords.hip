@@ -1,0 +1,428 @@
+// Coordinate maps on the GPU: packed-key open-addressing hash table, strided maps with
+// first-occurrence row order, neighbour tables and ballot/prefix-sum rule-book compaction.
+// Semantics: SURVEY.md 8(b); restated on the CPU in oracle/me_oracle.c (orc_unique_first,
+// orc_stride, orc_kernel_map, orc_pairs_from_nbr).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void lidog_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *lidog_last_error(void) { return g_err; }
+extern "C" int lidog_abi_version(void) { return 1; }
+
+extern "C" int64_t lidog_hash_capacity(int64_t n) {
+    int64_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    return cap;
+}
+
+// ------------------------------------------------------------------ block-level scans
+__device__ __forceinline__ int block_excl_scan_256(int v, int *total) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();  // protect wsum reuse across calls
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) off += wsum[i];
+        tot += wsum[i];
+    }
+    *total = tot;
+    return off + x - v;
+}
+
+// exclusive scan of int32 data[n] in place; sums[nb+1] scratch (nb = ceil(n/1024)); sums[nb] = total
+__global__ __launch_bounds__(256) void scan_block_sums(const int32_t *__restrict__ data, int64_t n,
+                                                       int32_t *__restrict__ sums) {
+    int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (base + j < n) v += data[base + j];
+    int tot;
+    block_excl_scan_256(v, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void scan_block_offsets(int32_t *__restrict__ sums, int64_t nb) {
+    // single block; chunked with carry
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t c = 0; c < nb; c += 256) {
+        int64_t i = c + threadIdx.x;
+        int v = (i < nb) ? sums[i] : 0;
+        int tot;
+        int ex = block_excl_scan_256(v, &tot);
+        int carry = carry_s;
+        if (i < nb) sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void scan_apply(int32_t *__restrict__ data, int64_t n,
+                                                  const int32_t *__restrict__ sums) {
+    int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = (base + j < n) ? data[base + j] : 0;
+        s += v[j];
+    }
+    int tot;
+    int ex = block_excl_scan_256(s, &tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (base + j < n) data[base + j] = ex;
+        ex += v[j];
+    }
+}
+
+static int device_exclusive_scan(int32_t *data, int64_t n, int32_t *sums, hipStream_t st) {
+    int64_t nb = cdiv64(n, 1024);
+    if (nb == 0) return 0;
+    scan_block_sums<<<dim3((unsigned)nb), 256, 0, st>>>(data, n, sums);
+    scan_block_offsets<<<1, 256, 0, st>>>(sums, nb);
+    scan_apply<<<dim3((unsigned)nb), 256, 0, st>>>(data, n, sums);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ insert
+__device__ __forceinline__ int32_t table_insert_min(uint64_t *keys, int32_t *vals, uint64_t mask, uint64_t key,
+                                                    int32_t row) {
+    uint64_t slot = lidog_mix(key) & mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)LIDOG_EMPTY_KEY,
+                                            (unsigned long long)key);
+        if (prev == LIDOG_EMPTY_KEY || prev == key) {
+            atomicMin(&vals[slot], row);
+            return (int32_t)slot;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_insert(const int4 *__restrict__ coords, int64_t n, int32_t stride,
+                                                uint64_t *keys, int32_t *vals, uint64_t mask,
+                                                int32_t *__restrict__ slot_of, int32_t *err_flag) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int4 c = coords[i];
+    if (stride > 1) {  // floor toward -inf; stride is a power-of-two multiple in practice but stay general
+        auto fl = [stride](int v) {
+            int q = v / stride;
+            if ((v % stride != 0) && (v < 0)) --q;
+            return q * stride;
+        };
+        c.y = fl(c.y); c.z = fl(c.z); c.w = fl(c.w);
+    }
+    int bad = 0;
+    uint64_t key = lidog_pack(c.x, c.y, c.z, c.w, &bad);
+    if (bad) { *err_flag = 1; slot_of[i] = -1; return; }
+    slot_of[i] = table_insert_min(keys, vals, mask, key, (int32_t)i);
+}
+
+__global__ __launch_bounds__(256) void k_first_row(int32_t *__restrict__ slot_then_first, int64_t n,
+                                                   const int32_t *__restrict__ vals,
+                                                   unsigned long long *n_unique) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int uniq = 0;
+    if (i < n) {
+        int s = slot_then_first[i];
+        int f = (s >= 0) ? vals[s] : (int)i;
+        slot_then_first[i] = f;
+        uniq = (f == (int)i);
+    }
+    unsigned long long m = __ballot(uniq);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_unique, (unsigned long long)__popcll(m));
+}
+
+extern "C" int lidog_coords_insert(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int64_t cap,
+                                   int32_t *first_row, int64_t *n_unique_dev, int32_t *err_flag, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, "coords_insert: cap must be a power of two >= 2n");
+    LIDOG_CHECK_HIP(hipMemsetAsync(keys, 0xff, sizeof(uint64_t) * cap, st));
+    LIDOG_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)vals, 0x7fffffff, cap, st));
+    LIDOG_CHECK_HIP(hipMemsetAsync(n_unique_dev, 0, sizeof(int64_t), st));
+    if (n == 0) return 0;
+    unsigned nb = (unsigned)cdiv64(n, 256);
+    k_insert<<<nb, 256, 0, st>>>((const int4 *)coords, n, 1, keys, vals, (uint64_t)(cap - 1), first_row, err_flag);
+    k_first_row<<<nb, 256, 0, st>>>(first_row, n, vals, (unsigned long long *)n_unique_dev);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ compaction of a map with duplicates
+__global__ __launch_bounds__(256) void k_flag_first(const int32_t *__restrict__ first_row, int64_t n,
+                                                    int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = (first_row[i] == (int)i);
+}
+
+__global__ __launch_bounds__(256) void k_compact_rows(const int32_t *__restrict__ first_row, int64_t n,
+                                                      const int32_t *__restrict__ rank, const int4 *coords,
+                                                      const uint64_t *keys, int32_t *vals, uint64_t mask,
+                                                      int32_t *__restrict__ unique_rows,
+                                                      int32_t *__restrict__ inverse) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int f = first_row[i];
+    int r = rank[f];
+    inverse[i] = r;
+    if (f == (int)i) {
+        unique_rows[r] = (int)i;
+        int4 c = coords[i];
+        int bad = 0;
+        uint64_t key = lidog_pack(c.x, c.y, c.z, c.w, &bad);
+        uint64_t slot = lidog_mix(key) & mask;
+        while (keys[slot] != key) slot = (slot + 1) & mask;
+        vals[slot] = r;
+    }
+}
+
+extern "C" int lidog_coords_compact(const int32_t *first_row, int64_t n, const uint64_t *keys, int32_t *vals,
+                                    int64_t cap, const int32_t *coords, int32_t *unique_rows, int32_t *inverse,
+                                    int32_t *scan_ws, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    unsigned nb = (unsigned)cdiv64(n, 256);
+    int32_t *rank = scan_ws, *sums = scan_ws + n;
+    k_flag_first<<<nb, 256, 0, st>>>(first_row, n, rank);
+    if (device_exclusive_scan(rank, n, sums, st)) return 1;
+    // vals still hold first rows while every thread reads rank[first_row]; the rewrite of vals only
+    // touches slots no other thread reads in this kernel
+    k_compact_rows<<<nb, 256, 0, st>>>(first_row, n, rank, (const int4 *)coords, keys, vals, (uint64_t)(cap - 1),
+                                       unique_rows, inverse);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ strided map
+__global__ __launch_bounds__(256) void k_stride_flag(const int32_t *__restrict__ slot_of, int64_t n,
+                                                     const int32_t *__restrict__ vals, int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        int s = slot_of[i];
+        flag[i] = (s >= 0 && vals[s] == (int)i);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stride_emit(const int4 *__restrict__ coords, int64_t n, int32_t stride,
+                                                     const int32_t *__restrict__ slot_of,
+                                                     const int32_t *__restrict__ vals,
+                                                     const int32_t *__restrict__ rank, int4 *__restrict__ coords_out,
+                                                     int32_t *__restrict__ parent2child, int64_t *n_out_dev) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int s = slot_of[i];
+    int f = (s >= 0) ? vals[s] : (int)i;
+    int r = rank[f];
+    parent2child[i] = r;
+    bool first = (f == (int)i);
+    if (first) {
+        int4 c = coords[i];
+        auto fl = [stride](int v) {
+            int q = v / stride;
+            if ((v % stride != 0) && (v < 0)) --q;
+            return q * stride;
+        };
+        c.y = fl(c.y); c.z = fl(c.z); c.w = fl(c.w);
+        coords_out[r] = c;
+    }
+    if (i == n - 1) *n_out_dev = (int64_t)rank[i] + (first ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_stride_rewrite(int64_t n, const int32_t *__restrict__ slot_of,
+                                                        int32_t *vals, const int32_t *__restrict__ rank,
+                                                        const int32_t *__restrict__ parent2child) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int s = slot_of[i];
+    // rank is the exclusive scan of the first-occurrence flags, so a row is a first occurrence
+    // exactly when its child row equals its own rank (later rows of the same child have rank > child)
+    if (s >= 0 && parent2child[i] == rank[i]) vals[s] = rank[i];
+}
+
+extern "C" int lidog_coords_stride(const int32_t *coords_in, int64_t n_in, int32_t new_stride, uint64_t *keys,
+                                   int32_t *vals, int64_t cap, int32_t *parent2child, int32_t *coords_out,
+                                   int64_t *n_out_dev, int32_t *ws, int32_t *err_flag, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(cap >= 2 * n_in && (cap & (cap - 1)) == 0, "coords_stride: cap must be a power of two >= 2n");
+    LIDOG_REQUIRE(n_in < 0x3fffffff, "coords_stride: too many rows");
+    LIDOG_CHECK_HIP(hipMemsetAsync(keys, 0xff, sizeof(uint64_t) * cap, st));
+    LIDOG_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)vals, 0x7fffffff, cap, st));
+    LIDOG_CHECK_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), st));
+    if (n_in == 0) return 0;
+    unsigned nb = (unsigned)cdiv64(n_in, 256);
+    int32_t *slot_of = ws, *rank = ws + n_in, *sums = ws + 2 * n_in;
+    k_insert<<<nb, 256, 0, st>>>((const int4 *)coords_in, n_in, new_stride, keys, vals, (uint64_t)(cap - 1), slot_of,
+                                 err_flag);
+    k_stride_flag<<<nb, 256, 0, st>>>(slot_of, n_in, vals, rank);
+    if (device_exclusive_scan(rank, n_in, sums, st)) return 1;
+    k_stride_emit<<<nb, 256, 0, st>>>((const int4 *)coords_in, n_in, new_stride, slot_of, vals, rank,
+                                      (int4 *)coords_out, parent2child, n_out_dev);
+    k_stride_rewrite<<<nb, 256, 0, st>>>(n_in, slot_of, vals, rank, parent2child);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ kernel map (neighbour table)
+struct KOffsets {
+    int32_t d[125 * 3];
+};
+
+__global__ __launch_bounds__(256) void k_kernel_map(const int4 *__restrict__ coords_out, int64_t n_out,
+                                                    const uint64_t *__restrict__ keys,
+                                                    const int32_t *__restrict__ vals, uint64_t mask, KOffsets offs,
+                                                    int32_t *__restrict__ nbr) {
+    // the 3x3x3 (or 5^3, 2^3) offset neighbourhood is staged in LDS once per workgroup
+    __shared__ int32_t s_off[125 * 3];
+    const int K = gridDim.y;
+    for (int t = threadIdx.x; t < K * 3; t += 256) s_off[t] = offs.d[t];
+    __syncthreads();
+    int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const int k = blockIdx.y;
+    int4 c = coords_out[o];
+    int bad = 0;
+    uint64_t key = lidog_pack(c.x, c.y + s_off[3 * k], c.z + s_off[3 * k + 1], c.w + s_off[3 * k + 2], &bad);
+    nbr[(int64_t)k * n_out + o] = bad ? -1 : lidog_find(keys, vals, mask, key);
+}
+
+extern "C" int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const uint64_t *in_keys,
+                                const int32_t *in_vals, int64_t in_cap, const int32_t *offsets_host, int32_t K,
+                                int32_t *nbr, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(K >= 1 && K <= 125, "kernel_map: K=%d out of range [1,125]", K);
+    if (n_out == 0) return 0;
+    KOffsets offs;
+    for (int i = 0; i < K * 3; ++i) offs.d[i] = offsets_host[i];
+    dim3 grid((unsigned)cdiv64(n_out, 256), (unsigned)K);
+    k_kernel_map<<<grid, 256, 0, st>>>((const int4 *)coords_out, n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), offs,
+                                       nbr);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ rule book (pairs) by ballot + prefix sum
+// cnt[k * nbp + b]: number of valid neighbours of offset k among rows [1024 b, 1024 (b+1))
+__global__ __launch_bounds__(256) void k_pairs_count(const int32_t *__restrict__ nbr, int64_t n_out, int nbp,
+                                                     int32_t *__restrict__ cnt) {
+    const int k = blockIdx.y, b = blockIdx.x;
+    __shared__ int wsum[4];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t o = (int64_t)b * 1024 + j * 256 + threadIdx.x;
+        bool v = (o < n_out) && (nbr[(int64_t)k * n_out + o] >= 0);
+        c += __popcll(__ballot(v));  // wave-uniform count
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(int64_t)k * nbp + b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one thread per k: exclusive scan over row blocks, then (thread 0) over k -> k_off
+__global__ __launch_bounds__(128) void k_pairs_scan(int32_t *__restrict__ cnt, int nbp, int K,
+                                                    int64_t *__restrict__ k_off, int32_t *__restrict__ totals) {
+    const int k = threadIdx.x;
+    if (k < K) {
+        int run = 0;
+        for (int b = 0; b < nbp; ++b) {
+            int v = cnt[(int64_t)k * nbp + b];
+            cnt[(int64_t)k * nbp + b] = run;
+            run += v;
+        }
+        totals[k] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int kk = 0; kk < K; ++kk) {
+            k_off[kk] = run;
+            run += totals[kk];
+        }
+        k_off[K] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pairs_emit(const int32_t *__restrict__ nbr, int64_t n_out, int64_t n_in,
+                                                    int nbp, const int32_t *__restrict__ cnt,
+                                                    const int64_t *__restrict__ k_off, int32_t *__restrict__ pair_in,
+                                                    int32_t *__restrict__ pair_out, int32_t *__restrict__ pos_out,
+                                                    int32_t *__restrict__ pos_in) {
+    const int k = blockIdx.y, b = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ int wcnt[4][4];  // [j][wave]
+    int nb_[4];
+    unsigned long long masks[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int64_t o = (int64_t)b * 1024 + j * 256 + threadIdx.x;
+        nb_[j] = (o < n_out) ? nbr[(int64_t)k * n_out + o] : -1;
+        masks[j] = __ballot(nb_[j] >= 0);
+        if (lane == 0) wcnt[j][w] = __popcll(masks[j]);
+    }
+    __syncthreads();
+    int64_t base = k_off[k] + cnt[(int64_t)k * nbp + b];
+    int run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int before = run;
+        for (int ww = 0; ww < 4; ++ww) {
+            if (ww < w) before += wcnt[j][ww];
+            run += wcnt[j][ww];
+        }
+        int64_t o = (int64_t)b * 1024 + j * 256 + threadIdx.x;
+        if (o < n_out) {
+            int32_t p = -1;
+            if (nb_[j] >= 0) {
+                int rank = before + __popcll(masks[j] & ((1ull << lane) - 1ull));
+                p = (int32_t)(base + rank);
+                pair_in[p] = nb_[j];
+                pair_out[p] = (int32_t)o;
+                pos_in[(int64_t)k * n_in + nb_[j]] = p;
+            }
+            pos_out[(int64_t)k * n_out + o] = p;
+        }
+    }
+}
+
+extern "C" int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t K,
+                                      int64_t *k_off_dev, int32_t *pair_in, int32_t *pair_out, int32_t *pos_out,
+                                      int32_t *pos_in, int32_t *ws, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(K >= 1 && K <= 125, "kernel_map_pairs: K=%d out of range [1,125]", K);
+    LIDOG_REQUIRE(n_out * (int64_t)K < 0x7fffffff, "kernel_map_pairs: pair positions overflow int32");
+    LIDOG_CHECK_HIP(hipMemsetAsync(pos_in, 0xff, sizeof(int32_t) * n_in * K, st));
+    if (n_out == 0) {
+        LIDOG_CHECK_HIP(hipMemsetAsync(k_off_dev, 0, sizeof(int64_t) * (K + 1), st));
+        return 0;
+    }
+    int nbp = (int)cdiv64(n_out, 1024);
+    int32_t *cnt = ws, *totals = ws + (int64_t)nbp * K;
+    dim3 grid((unsigned)nbp, (unsigned)K);
+    k_pairs_count<<<grid, 256, 0, st>>>(nbr, n_out, nbp, cnt);
+    k_pairs_scan<<<1, 128, 0, st>>>(cnt, nbp, K, k_off_dev, totals);
+    k_pairs_emit<<<grid, 256, 0, st>>>(nbr, n_out, n_in, nbp, cnt, k_off_dev, pair_in, pair_out, pos_out, pos_in);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,433 @@
+// Sparse convolution on the rule book: gathered GEMM (fp32 vector FMA, LDS-tiled for 64-wide
+// waves) -> per-output-row reduction in ascending kernel-offset order (no atomics, bit-reproducible),
+// weight gradient by split reduction over pairs.  CPU restatement: oracle/me_oracle.c
+// (orc_conv_fwd / orc_conv_bwd_data / orc_conv_bwd_weight).
+#include "common.h"
+
+// ------------------------------------------------------------------ gathered GEMM
+// Tile: 128 pair-rows x (16*CN) columns, BK = 32 input channels per step, 256 threads as 16 (ty) x 16 (tx).
+// Thread (ty,tx) owns rows ty + 16*i (i<8) and columns tx*CN .. tx*CN+CN-1.
+// A tile in LDS row-major with stride 36 floats: the four ty of a wave read rows 36 floats apart ->
+// distinct banks for ds_read_b128; the 16 tx of one ty read the same address (broadcast).
+#define GM_TM 128
+#define GM_BK 32
+#define GM_SA 36
+
+template <int CN>
+__global__ __launch_bounds__(256) void k_sconv_gemm(const float *__restrict__ A, const int32_t *__restrict__ gather,
+                                                    const float *__restrict__ B, const float *__restrict__ bias,
+                                                    const int32_t *__restrict__ tile_k,
+                                                    const int32_t *__restrict__ tile_row0,
+                                                    const int32_t *__restrict__ tile_rows, int Cin, int Cout,
+                                                    float *__restrict__ T, const int32_t *__restrict__ scatter) {
+    constexpr int TN = 16 * CN;
+    constexpr int BV = (GM_BK * TN / 4) / 256 > 0 ? (GM_BK * TN / 4) / 256 : 1;  // float4 of B per thread
+    __shared__ __attribute__((aligned(16))) float As[GM_TM * GM_SA];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BK * TN];
+    __shared__ int32_t s_src[GM_TM];
+
+    const int tile = blockIdx.x;
+    const int k = tile_k[tile];
+    const int row0 = tile_row0[tile];
+    const int rows = tile_rows[tile];
+    const int col0 = blockIdx.y * TN;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+
+    if (tid < GM_TM) {
+        int r = tid;
+        int src = -1;
+        if (r < rows) src = gather ? gather[row0 + r] : (row0 + r);
+        s_src[r] = src;
+    }
+    __syncthreads();
+
+    const float *Bk = B + (size_t)k * Cin * Cout + col0;
+
+    // global -> register staging: A: 128 rows x 8 float4 = 1024 float4 -> 4 per thread (8 lanes per row)
+    float4 ra[4];
+    float4 rb[BV];
+    auto load_chunk = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int f = tid + 256 * j;
+            int r = f >> 3, q = f & 7;
+            int src = s_src[r];
+            ra[j] = (src >= 0) ? *reinterpret_cast<const float4 *>(A + (size_t)src * Cin + kb + q * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            int f = tid + 256 * j;
+            if (f < GM_BK * TN / 4) {
+                int kk = f / (TN / 4), c4 = f % (TN / 4);
+                rb[j] = *reinterpret_cast<const float4 *>(Bk + (size_t)(kb + kk) * Cout + c4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int f = tid + 256 * j;
+            int r = f >> 3, q = f & 7;
+            *reinterpret_cast<float4 *>(&As[r * GM_SA + q * 4]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BV; ++j) {
+            int f = tid + 256 * j;
+            if (f < GM_BK * TN / 4) *reinterpret_cast<float4 *>(&Bs[f * 4]) = rb[j];
+        }
+    };
+
+    float acc[8][CN];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = 0.f;
+
+    load_chunk(0);
+    for (int kb = 0; kb < Cin; kb += GM_BK) {
+        __syncthreads();  // previous chunk fully consumed
+        store_chunk();
+        __syncthreads();
+        if (kb + GM_BK < Cin) load_chunk(kb + GM_BK);  // overlaps with the FMAs below
+#pragma unroll
+        for (int k4 = 0; k4 < GM_BK; k4 += 4) {
+            float4 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const float4 *>(&As[(ty + 16 * i) * GM_SA + k4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float b[CN];
+                if constexpr (CN % 4 == 0) {
+#pragma unroll
+                    for (int j = 0; j < CN; j += 4) {
+                        float4 v = *reinterpret_cast<const float4 *>(&Bs[(k4 + s) * TN + tx * CN + j]);
+                        b[j] = v.x; b[j + 1] = v.y; b[j + 2] = v.z; b[j + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CN; j += 2) {
+                        float2 v = *reinterpret_cast<const float2 *>(&Bs[(k4 + s) * TN + tx * CN + j]);
+                        b[j] = v.x; b[j + 1] = v.y;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float av = (s == 0) ? a[i].x : (s == 1) ? a[i].y : (s == 2) ? a[i].z : a[i].w;
+#pragma unroll
+                    for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_fmaf(av, b[j], acc[i][j]);
+                }
+            }
+        }
+    }
+
+    // epilogue: one coalesced row segment per (row, tx)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int r = ty + 16 * i;
+        if (r < rows) {
+            size_t dst = scatter ? (size_t)scatter[row0 + r] : (size_t)(row0 + r);
+            float *out = T + dst * Cout + col0 + tx * CN;
+#pragma unroll
+            for (int j = 0; j < CN; j += 2) {
+                float2 v = make_float2(acc[i][j], acc[i][j + 1]);
+                if (bias) { v.x += bias[col0 + tx * CN + j]; v.y += bias[col0 + tx * CN + j + 1]; }
+                *reinterpret_cast<float2 *>(out + j) = v;
+            }
+        }
+    }
+}
+
+// any shape: one thread per (row, column); used for Cin=1 (stem) and Cout=7 (final)
+__global__ __launch_bounds__(256) void k_sconv_gemm_small(const float *__restrict__ A,
+                                                          const int32_t *__restrict__ gather,
+                                                          const float *__restrict__ B,
+                                                          const float *__restrict__ bias,
+                                                          const int32_t *__restrict__ tile_k,
+                                                          const int32_t *__restrict__ tile_row0,
+                                                          const int32_t *__restrict__ tile_rows, int Cin, int Cout,
+                                                          float *__restrict__ T,
+                                                          const int32_t *__restrict__ scatter) {
+    const int tile = blockIdx.x;
+    const int k = tile_k[tile], row0 = tile_row0[tile], rows = tile_rows[tile];
+    const float *Bk = B + (size_t)k * Cin * Cout;
+    for (int e = threadIdx.x; e < rows * Cout; e += 256) {
+        int r = e / Cout, c = e % Cout;
+        int src = gather ? gather[row0 + r] : (row0 + r);
+        const float *x = A + (size_t)src * Cin;
+        float t = 0.f;
+        for (int ci = 0; ci < Cin; ++ci) t = __builtin_fmaf(x[ci], Bk[(size_t)ci * Cout + c], t);
+        if (bias) t += bias[c];
+        size_t dst = scatter ? (size_t)scatter[row0 + r] : (size_t)(row0 + r);
+        T[dst * Cout + c] = t;
+    }
+}
+
+extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
+                                const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows,
+                                int32_t n_tiles, int32_t Cin, int32_t Cout, float *T, const int32_t *scatter,
+                                void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_tiles == 0) return 0;
+    LIDOG_REQUIRE(Cin > 0 && Cout > 0, "sconv_gemm: bad channel counts %d %d", Cin, Cout);
+    int cn = 0;
+    if (Cin % GM_BK == 0) {
+        if (Cout % 128 == 0) cn = 8;
+        else if (Cout % 96 == 0) cn = 6;
+        else if (Cout % 64 == 0) cn = 4;
+        else if (Cout % 32 == 0) cn = 2;
+    }
+#define LAUNCH_GEMM(CN_)                                                                                      \
+    k_sconv_gemm<CN_><<<dim3((unsigned)n_tiles, (unsigned)(Cout / (16 * CN_))), 256, 0, st>>>(               \
+        A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter)
+    switch (cn) {
+        case 8: LAUNCH_GEMM(8); break;
+        case 6: LAUNCH_GEMM(6); break;
+        case 4: LAUNCH_GEMM(4); break;
+        case 2: LAUNCH_GEMM(2); break;
+        default:
+            k_sconv_gemm_small<<<dim3((unsigned)n_tiles), 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0,
+                                                                        tile_rows, Cin, Cout, T, scatter);
+    }
+#undef LAUNCH_GEMM
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ per-row reduction over kernel offsets
+__global__ __launch_bounds__(256) void k_sconv_reduce4(const float4 *__restrict__ T, const int32_t *__restrict__ pos,
+                                                       int64_t n, int K, int C4, const float4 *__restrict__ bias,
+                                                       float4 *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * C4) return;
+    int64_t o = idx / C4;
+    int c4 = (int)(idx % C4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+        int p = pos[(int64_t)k * n + o];
+        if (p >= 0) {
+            float4 t = T[(int64_t)p * C4 + c4];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+    }
+    if (bias) {
+        float4 b = bias[c4];
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    out[idx] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_sconv_reduce1(const float *__restrict__ T, const int32_t *__restrict__ pos,
+                                                       int64_t n, int K, int C, const float *__restrict__ bias,
+                                                       float *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * C) return;
+    int64_t o = idx / C;
+    int c = (int)(idx % C);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        int p = pos[(int64_t)k * n + o];
+        if (p >= 0) acc += T[(int64_t)p * C + c];
+    }
+    if (bias) acc += bias[c];
+    out[idx] = acc;
+}
+
+extern "C" int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C,
+                                  const float *bias, float *out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    if (C % 4 == 0) {
+        int C4 = C / 4;
+        k_sconv_reduce4<<<(unsigned)cdiv64(n * C4, 256), 256, 0, st>>>((const float4 *)T, pos, n, K, C4,
+                                                                       (const float4 *)bias, (float4 *)out);
+    } else {
+        k_sconv_reduce1<<<(unsigned)cdiv64(n * C, 256), 256, 0, st>>>(T, pos, n, K, C, bias, out);
+    }
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ weight gradient
+// gW[k][ci][co] = sum_p A[pa[p]][ci] * G[pg[p]][co] over segment k.  Tile (16*RM) x (16*CN) of one k,
+// pairs processed 32 at a time through LDS (rows stay row-major: no transpose needed for an outer product).
+#define WG_R 32
+template <int RM, int CN>
+__global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A, const int32_t *__restrict__ pa,
+                                                     const float *__restrict__ G, const int32_t *__restrict__ pg,
+                                                     const int64_t *__restrict__ k_off, int K, int Cin, int Cout,
+                                                     int n_split, float *__restrict__ partial) {
+    constexpr int TM = 16 * RM, TN = 16 * CN;
+    __shared__ __attribute__((aligned(16))) float As[WG_R * TM];
+    __shared__ __attribute__((aligned(16))) float Gs[WG_R * TN];
+    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int tiles_n = Cout / TN;
+    const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
+    const int64_t len = seg1 - seg0;
+    const int64_t per = ((len + n_split - 1) / n_split + WG_R - 1) / WG_R * WG_R;
+    const int64_t p0 = seg0 + (int64_t)split * per;
+    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+
+    float acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = 0.f;
+
+    constexpr int AV = (WG_R * TM / 4 + 255) / 256, GV = (WG_R * TN / 4 + 255) / 256;
+    for (int64_t p = p0; p < p1; p += WG_R) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            int f = tid + 256 * j;
+            if (f < WG_R * TM / 4) {
+                int r = f / (TM / 4), c4 = f % (TM / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p + r < p1) v = *reinterpret_cast<const float4 *>(A + (size_t)pa[p + r] * Cin + ci0 + c4 * 4);
+                *reinterpret_cast<float4 *>(&As[r * TM + c4 * 4]) = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            int f = tid + 256 * j;
+            if (f < WG_R * TN / 4) {
+                int r = f / (TN / 4), c4 = f % (TN / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p + r < p1) v = *reinterpret_cast<const float4 *>(G + (size_t)pg[p + r] * Cout + co0 + c4 * 4);
+                *reinterpret_cast<float4 *>(&Gs[r * TN + c4 * 4]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < WG_R; ++r) {
+            float a[RM], g[CN];
+#pragma unroll
+            for (int i = 0; i < RM; i += 2) {
+                float2 v = *reinterpret_cast<const float2 *>(&As[r * TM + ty * RM + i]);
+                a[i] = v.x; a[i + 1] = v.y;
+            }
+#pragma unroll
+            for (int j = 0; j < CN; j += 2) {
+                float2 v = *reinterpret_cast<const float2 *>(&Gs[r * TN + tx * CN + j]);
+                g[j] = v.x; g[j + 1] = v.y;
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_fmaf(a[i], g[j], acc[i][j]);
+        }
+    }
+    float *dst = partial + ((size_t)split * K + k) * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+        float *row = dst + (size_t)(ci0 + ty * RM + i) * Cout + co0 + tx * CN;
+#pragma unroll
+        for (int j = 0; j < CN; j += 2) *reinterpret_cast<float2 *>(row + j) = make_float2(acc[i][j], acc[i][j + 1]);
+    }
+}
+
+// generic fallback: one thread per (k, ci, co) sweeping its split of the segment
+__global__ __launch_bounds__(256) void k_sconv_wgrad_small(const float *__restrict__ A,
+                                                           const int32_t *__restrict__ pa,
+                                                           const float *__restrict__ G,
+                                                           const int32_t *__restrict__ pg,
+                                                           const int64_t *__restrict__ k_off, int K, int Cin,
+                                                           int Cout, int n_split, float *__restrict__ partial) {
+    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
+    const int64_t per = (seg1 - seg0 + n_split - 1) / n_split;
+    const int64_t p0 = seg0 + (int64_t)split * per;
+    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < Cin * Cout; e += 256 * gridDim.y) {
+        int ci = e / Cout, co = e % Cout;
+        float acc = 0.f;
+        for (int64_t p = p0; p < p1; ++p)
+            acc = __builtin_fmaf(A[(size_t)pa[p] * Cin + ci], G[(size_t)pg[p] * Cout + co], acc);
+        partial[((size_t)split * K + k) * Cin * Cout + e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_split_sum(const float *__restrict__ partial, int64_t n, int n_split,
+                                                   float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = partial[i];
+    for (int s = 1; s < n_split; ++s) acc += partial[(int64_t)s * n + i];
+    out[i] = acc;
+}
+
+static int pick_tile(int C) {
+    if (C % 128 == 0) return 8;
+    if (C % 96 == 0) return 6;
+    if (C % 64 == 0) return 4;
+    if (C % 32 == 0) return 2;
+    return 0;
+}
+
+template <int RM>
+static void launch_wgrad_rm(int cn, dim3 grid, hipStream_t st, const float *A, const int32_t *pa, const float *G,
+                            const int32_t *pg, const int64_t *k_off, int K, int Cin, int Cout, int n_split,
+                            float *partial) {
+    switch (cn) {
+        case 8: k_sconv_wgrad<RM, 8><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial); break;
+        case 6: k_sconv_wgrad<RM, 6><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial); break;
+        case 4: k_sconv_wgrad<RM, 4><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial); break;
+        default: k_sconv_wgrad<RM, 2><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial);
+    }
+}
+
+extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
+                                 const int64_t *k_off_dev, int32_t K, int32_t Cin, int32_t Cout, int32_t n_split,
+                                 float *partial, float *gW, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(n_split >= 1 && K >= 1, "sconv_wgrad: bad n_split/K");
+    int rm = pick_tile(Cin), cn = pick_tile(Cout);
+    float *dst = (n_split == 1) ? gW : partial;
+    if (rm && cn) {
+        dim3 grid((unsigned)(K * n_split), (unsigned)((Cin / (16 * rm)) * (Cout / (16 * cn))));
+        switch (rm) {
+            case 8: launch_wgrad_rm<8>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
+            case 6: launch_wgrad_rm<6>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
+            case 4: launch_wgrad_rm<4>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
+            default: launch_wgrad_rm<2>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst);
+        }
+    } else {
+        int by = (Cin * Cout + 255) / 256;
+        if (by > 64) by = 64;
+        k_sconv_wgrad_small<<<dim3((unsigned)(K * n_split), (unsigned)by), 256, 0, st>>>(
+            A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst);
+    }
+    if (n_split > 1) {
+        int64_t n = (int64_t)K * Cin * Cout;
+        k_split_sum<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(partial, n, n_split, gW);
+    }
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ Wt[k][co][ci] = W[k][ci][co]
+__global__ __launch_bounds__(256) void k_transpose(const float *__restrict__ W, int Cin, int Cout,
+                                                   float *__restrict__ Wt) {
+    __shared__ float tile[32][33];
+    const int k = blockIdx.z;
+    const float *src = W + (size_t)k * Cin * Cout;
+    float *dst = Wt + (size_t)k * Cin * Cout;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8)
+        if (ci0 + r < Cin && co0 + tx < Cout) tile[r][tx] = src[(size_t)(ci0 + r) * Cout + co0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (co0 + r < Cout && ci0 + tx < Cin) dst[(size_t)(co0 + r) * Cin + ci0 + tx] = tile[tx][r];
+}
+
+extern "C" int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout, float *Wt,
+                                      void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((Cout + 31) / 32), (unsigned)((Cin + 31) / 32), (unsigned)K);
+    k_transpose<<<grid, 256, 0, st>>>(W, Cin, Cout, Wt);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,635 @@
+"""MinkowskiEngine-compatible operator API on MI355X (HIP kernels behind include/lidog_amd.h).
+
+Mirrors the surface of MinkowskiEngine 0.5.4 that LiDOG's models and pipelines use
+(SURVEY.md 8(b)); reference call sites:
+  SparseTensor(coordinates=..., features=...)        utils/pipelines/trainer_lighting_2d.py:151
+  MinkowskiConvolution / ...Transpose                utils/models/minkunet_bev.py:57-123
+  MinkowskiBatchNorm(.bn) / MinkowskiSyncBatchNorm   minkunet_bev.py:60,406-408; train_lidog.py:228
+  MinkowskiReLU(inplace=True), cat, +=               minkunet_bev.py:124,337; resnet_block.py:52
+  utils.kaiming_normal_                              minkunet_bev.py:404
+  modules.resnet_block.BasicBlock                    minkunet_bev.py:4,425-439
+
+`install_as_minkowski_engine()` registers this module as `MinkowskiEngine` so the reference's
+`import MinkowskiEngine as ME` resolves to it.  Everything runs on the GPU through the C ABI; there
+is no CPU path (tensors on the CPU raise).
+"""
+import math
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+
+TILE_ROWS = 128  # GM_TM of csrc/sconv.hip
+
+
+def kernel_offsets(kernel_size, tensor_stride, dilation=1):
+    """[K,3] int32 (x,y,z), index x fastest; odd sizes centred, even sizes start at 0."""
+    k = int(kernel_size)
+    if k % 2 == 1:
+        r = [(-(k // 2) + i) * tensor_stride * dilation for i in range(k)]
+    else:
+        r = [i * tensor_stride * dilation for i in range(k)]
+    return np.array([(x, y, z) for z in r for y in r for x in r], dtype=np.int32)
+
+
+def _tiles(k_off_host, device):
+    """tile descriptors (tile_k, tile_row0, tile_rows) for 128-row tiles that never straddle an offset"""
+    k_off = np.asarray(k_off_host, dtype=np.int64)
+    cnt = np.diff(k_off)
+    nt = (cnt + TILE_ROWS - 1) // TILE_ROWS
+    total = int(nt.sum())
+    if total == 0:
+        return torch.zeros((3, 0), dtype=torch.int32, device=device), 0
+    tile_k = np.repeat(np.arange(len(cnt), dtype=np.int64), nt)
+    first = np.repeat(np.cumsum(nt) - nt, nt)
+    within = np.arange(total, dtype=np.int64) - first
+    row0 = k_off[tile_k] + within * TILE_ROWS
+    rows = np.minimum(TILE_ROWS, k_off[tile_k + 1] - row0)
+    desc = np.stack([tile_k, row0, rows]).astype(np.int32)
+    return torch.from_numpy(desc).to(device), total
+
+
+class _CoordMap:
+    __slots__ = ("coords", "keys", "vals", "cap", "n")
+
+    def __init__(self, coords, keys, vals, cap):
+        self.coords, self.keys, self.vals, self.cap, self.n = coords, keys, vals, cap, coords.shape[0]
+
+
+class KernelMap:
+    """Rule book of one (in map, out map, kernel) triple; see include/lidog_amd.h:lidog_kernel_map_pairs."""
+
+    def __init__(self, K, n_in, n_out, k_off, k_off_host, pair_in, pair_out, pos_out, pos_in, nbr):
+        self.K, self.n_in, self.n_out = K, n_in, n_out
+        self.k_off, self.k_off_host = k_off, k_off_host
+        self.P = int(k_off_host[-1])
+        self.pair_in, self.pair_out, self.pos_out, self.pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
+        self.tiles, self.n_tiles = _tiles(k_off_host, pair_in.device)
+
+
+class _IdentityMap:
+    """tile descriptors / pair lists of a 1x1 convolution over n rows (K = 1, in row == out row)"""
+
+    def __init__(self, n, device):
+        self.K, self.n_in, self.n_out, self.P = 1, n, n, n
+        self.k_off_host = [0, n]
+        self.k_off = torch.tensor([0, n], dtype=torch.int64, device=device)
+        self.rows = torch.arange(n, dtype=torch.int32, device=device)
+        self.tiles, self.n_tiles = _tiles(self.k_off_host, device)
+
+
+class CoordinateManager:
+    """Coordinate maps keyed by tensor stride, kernel maps cached per (in, out, kernel, dilation)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.maps = {}
+        self.kmaps = {}
+        self.identity = {}
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        self.batch_size = None
+
+    def _check(self):
+        if int(self.err.item()) != 0:
+            raise ValueError("coordinates out of the supported range: |x|,|y|,|z| <= 65535, 0 <= batch <= 4095")
+
+    def insert(self, coords):
+        _lib.require_gpu(coords, "coordinates")
+        coords = coords.contiguous()
+        n = coords.shape[0]
+        cap = _lib.load().lidog_hash_capacity(n)
+        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+        vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+        first = torch.empty(n, dtype=torch.int32, device=self.device)
+        n_unique = torch.zeros(1, dtype=torch.int64, device=self.device)
+        call("lidog_coords_insert", ptr(coords), n, ptr(keys), ptr(vals), cap, ptr(first), ptr(n_unique),
+             ptr(self.err))
+        stats = torch.stack([n_unique[0], self.err[0].long(), coords[:, 0].max().long() if n else n_unique[0]]).tolist()
+        if stats[1] != 0:
+            self._check()
+        self.batch_size = int(stats[2]) + 1 if n else 0
+        uniq = inv = None
+        if stats[0] != n:  # duplicates: keep the first occurrence, rows in first-occurrence order
+            m = int(stats[0])
+            uniq_full = torch.empty(n, dtype=torch.int32, device=self.device)
+            inv = torch.empty(n, dtype=torch.int32, device=self.device)
+            ws = torch.empty(n + 2048, dtype=torch.int32, device=self.device)
+            call("lidog_coords_compact", ptr(first), n, ptr(keys), ptr(vals), cap, ptr(coords), ptr(uniq_full),
+                 ptr(inv), ptr(ws))
+            uniq = uniq_full[:m]
+            coords = coords[uniq.long()].contiguous()
+        self.maps[1] = _CoordMap(coords, keys, vals, cap)
+        return uniq, inv
+
+    def stride(self, s_in, s_out):
+        if s_out in self.maps:
+            return self.maps[s_out]
+        src = self.maps[s_in]
+        n = src.n
+        cap = _lib.load().lidog_hash_capacity(n)
+        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+        vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+        p2c = torch.empty(n, dtype=torch.int32, device=self.device)
+        out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        n_out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ws = torch.empty(2 * n + 2048, dtype=torch.int32, device=self.device)
+        call("lidog_coords_stride", ptr(src.coords), n, int(s_out), ptr(keys), ptr(vals), cap, ptr(p2c), ptr(out),
+             ptr(n_out), ptr(ws), ptr(self.err))
+        m = int(n_out.item())
+        self.maps[s_out] = _CoordMap(out[:m], keys, vals, cap)  # out[:m] stays contiguous (leading rows)
+        return self.maps[s_out]
+
+    def kernel_map(self, s_in, s_out, kernel_size, dilation=1):
+        key = (s_in, s_out, kernel_size, dilation)
+        if key in self.kmaps:
+            return self.kmaps[key]
+        cin = self.maps[s_in]
+        cout = cin if s_out == s_in else self.stride(s_in, s_out)
+        offs = kernel_offsets(kernel_size, s_in, dilation)
+        K = offs.shape[0]
+        n_in, n_out = cin.n, cout.n
+        nbr = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
+        call("lidog_kernel_map", ptr(cout.coords), n_out, ptr(cin.keys), ptr(cin.vals), cin.cap,
+             offs.ctypes.data, K, ptr(nbr))
+        k_off = torch.empty(K + 1, dtype=torch.int64, device=self.device)
+        pair_in = torch.empty(n_out * K, dtype=torch.int32, device=self.device)
+        pair_out = torch.empty(n_out * K, dtype=torch.int32, device=self.device)
+        pos_out = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
+        pos_in = torch.empty((K, n_in), dtype=torch.int32, device=self.device)
+        nbp = (n_out + 1023) // 1024
+        ws = torch.empty((nbp + 1) * K + K + 2, dtype=torch.int32, device=self.device)
+        call("lidog_kernel_map_pairs", ptr(nbr), n_out, n_in, K, ptr(k_off), ptr(pair_in), ptr(pair_out),
+             ptr(pos_out), ptr(pos_in), ptr(ws))
+        k_off_host = k_off.tolist()  # one synchronisation per kernel map (10 per MinkUNet34 forward)
+        P = int(k_off_host[-1])
+        km = KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr)
+        self.kmaps[key] = km
+        return km
+
+    def identity_map(self, n):
+        if n not in self.identity:
+            self.identity[n] = _IdentityMap(n, self.device)
+        return self.identity[n]
+
+
+class SparseTensor:
+    def __init__(self, features=None, coordinates=None, coordinate_manager=None, coordinate_map_key=None,
+                 tensor_stride=1, **_unused):
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("SparseTensor needs coordinates or a coordinate manager")
+            if coordinates.dtype != torch.int32:
+                raise ValueError("coordinates must be int32 (cast with .int(), as trainer_lighting_2d.py:151 does)")
+            _lib.require_gpu(coordinates, "coordinates")
+            _lib.require_gpu(features, "features")
+            coordinate_manager = CoordinateManager(coordinates.device)
+            uniq, _ = coordinate_manager.insert(coordinates)
+            if uniq is not None:
+                features = features[uniq.long()]
+            coordinate_map_key = 1
+        self.coordinate_manager = coordinate_manager
+        self.coordinate_map_key = coordinate_map_key if coordinate_map_key is not None else tensor_stride
+        self._F = features
+
+    F = property(lambda self: self._F)
+    C = property(lambda self: self.coordinate_manager.maps[self.coordinate_map_key].coords)
+    device = property(lambda self: self._F.device)
+    shape = property(lambda self: self._F.shape)
+    tensor_stride = property(lambda self: [self.coordinate_map_key] * 3)
+
+    def _like(self, feats):
+        return SparseTensor(feats, coordinate_manager=self.coordinate_manager,
+                            coordinate_map_key=self.coordinate_map_key)
+
+    def _same_map(self, other):
+        if other.coordinate_map_key != self.coordinate_map_key or \
+                other.coordinate_manager is not self.coordinate_manager:
+            raise ValueError("sparse tensors must share the coordinate map")
+
+    def __iadd__(self, other):
+        self._same_map(other)
+        self._F = _AddFn.apply(self._F, other._F)
+        return self
+
+    def __add__(self, other):
+        self._same_map(other)
+        return self._like(_AddFn.apply(self._F, other._F))
+
+
+def cat(*tensors):
+    for t in tensors[1:]:
+        tensors[0]._same_map(t)
+    return tensors[0]._like(torch.cat([t.F for t in tensors], dim=1))
+
+
+# ------------------------------------------------------------------ autograd functions over the C ABI
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        call("lidog_add", ptr(a), ptr(b), a.numel(), ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class _ReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inplace):
+        x = x.contiguous()
+        y = x if inplace else torch.empty_like(x)
+        call("lidog_relu_fwd", ptr(x), x.numel(), ptr(y))
+        if inplace:
+            ctx.mark_dirty(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        call("lidog_relu_bwd", ptr(g), ptr(y), g.numel(), ptr(dx))
+        return dx, None
+
+
+def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter):
+    call("lidog_sconv_gemm", ptr(A), ptr(gather), ptr(B), ptr(bias), ptr(m.tiles[0]), ptr(m.tiles[1]),
+         ptr(m.tiles[2]), m.n_tiles, Cin, Cout, ptr(out), ptr(scatter))
+
+
+def _wgrad_splits(K, Cin, Cout, P):
+    def tile(c):
+        for t in (128, 96, 64, 32):
+            if c % t == 0:
+                return t
+        return c
+    tiles = max(1, (Cin // tile(Cin)) * (Cout // tile(Cout)))
+    s = max(1, -(-1024 // (K * tiles)))
+    s = min(s, 64, max(1, P // (K * 256)))
+    return s
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out = conv(x) over a rule book.  `single_out`: every output row has exactly one pair (transposed
+    k2 s2) -> the GEMM scatters straight into `out`; `single_in`: every input row has exactly one pair
+    (k2 s2) -> the data gradient scatters straight into `gin`."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, m, swap, single_out, single_in):
+        x = x.contiguous()
+        W3 = W.contiguous().view(m.K, W.shape[-2], W.shape[-1])
+        K, Cin, Cout = W3.shape
+        identity = isinstance(m, _IdentityMap)
+        if identity:
+            g_in = g_out = None
+            n_out = m.n_out
+        elif not swap:
+            g_in, g_out, pos_o, n_out = m.pair_in, m.pair_out, m.pos_out, m.n_out
+        else:  # transposed convolution: the forward map used with in/out exchanged
+            g_in, g_out, pos_o, n_out = m.pair_out, m.pair_in, m.pos_in, m.n_in
+        out = torch.empty((n_out, Cout), dtype=torch.float32, device=x.device)
+        if identity:
+            _gemm(x, None, W3, bias, m, Cin, Cout, out, None)
+        elif single_out:
+            _gemm(x, g_in, W3, bias, m, Cin, Cout, out, g_out)
+        else:
+            T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
+            _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
+            call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
+        ctx.save_for_backward(x, W3)
+        ctx.m, ctx.swap, ctx.single_in, ctx.has_bias, ctx.w_shape = m, swap, single_in, bias is not None, W.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, W3 = ctx.saved_tensors
+        m, swap = ctx.m, ctx.swap
+        K, Cin, Cout = W3.shape
+        gout = gout.contiguous()
+        identity = isinstance(m, _IdentityMap)
+        if identity:
+            g_in = g_out = m.rows
+            pos_i, n_in = None, m.n_in
+        elif not swap:
+            g_in, g_out, pos_i, n_in = m.pair_in, m.pair_out, m.pos_in, m.n_in
+        else:
+            g_in, g_out, pos_i, n_in = m.pair_out, m.pair_in, m.pos_out, m.n_out
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            Wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
+            call("lidog_transpose_kernel", ptr(W3), K, Cin, Cout, ptr(Wt))
+            gx = torch.empty((n_in, Cin), dtype=torch.float32, device=x.device)
+            if identity:
+                _gemm(gout, None, Wt, None, m, Cout, Cin, gx, None)
+            elif ctx.single_in:
+                _gemm(gout, g_out, Wt, None, m, Cout, Cin, gx, g_in)
+            else:
+                T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
+                _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
+                call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(gx))
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty_like(W3)
+            ns = _wgrad_splits(K, Cin, Cout, m.P)
+            partial = torch.empty((ns, K, Cin, Cout), dtype=torch.float32, device=x.device) if ns > 1 else None
+            call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(m.k_off), K, Cin, Cout, ns,
+                 ptr(partial), ptr(gW))
+            gW = gW.view(ctx.w_shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gout.sum(dim=0, keepdim=True)
+        return gx, gW, gb, None, None, None, None
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """BatchNorm over rows ([n,C], hw=1) or NCHW images (hw=H*W), optional fused residual add and ReLU.
+    `group`: torch.distributed process group for SyncBatchNorm statistics (None = local)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, hw, relu, residual, group):
+        x = x.contiguous()
+        if hw == 1:
+            n, C = x.shape
+        else:
+            n, C = x.shape[0], x.shape[1]
+        count = float(n * hw)
+        dev = x.device
+        if training:
+            sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums))
+            if group is not None:
+                import torch.distributed as dist
+                packed = torch.cat([sums, torch.tensor([count], dtype=torch.float64, device=dev)])
+                dist.all_reduce(packed, group=group)
+                sums, count = packed[:-1].contiguous(), float(packed[-1].item())
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            call("lidog_bn_finalize", ptr(sums), count, C, float(eps), float(momentum), ptr(mean), ptr(invstd),
+                 ptr(running_mean), ptr(running_var))
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        y = torch.empty_like(x)
+        res = residual.contiguous() if residual is not None else None
+        call("lidog_bn_apply", ptr(x), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(res),
+             1 if relu else 0, ptr(y))
+        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+        ctx.cfg = (n, C, hw, count, training, residual is not None, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, invstd, y = ctx.saved_tensors
+        n, C, hw, count, training, has_res, group = ctx.cfg
+        dy = dy.contiguous()
+        dev = x.device
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums))
+        dw = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        local = sums
+        if not training:
+            # running statistics are constants: dx = dy' * w * invstd
+            red = torch.zeros_like(sums)
+        elif group is not None:
+            import torch.distributed as dist
+            red = sums.clone()
+            dist.all_reduce(red, group=group)
+        else:
+            red = sums
+        call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(red),
+             count, ptr(dx), ptr(dres), None, None)
+        # parameter gradients come from the LOCAL sums (DDP averages them afterwards)
+        db = local[:C].float()
+        dw = local[C:].float()
+        return dx, dw, db, None, None, None, None, None, None, None, dres, None
+
+
+def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None):
+    """functional entry used by the modules below and by lidog_amd.bev_head"""
+    training = bn.training or not bn.track_running_stats
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
+                              hw, relu, residual, group)
+
+
+# ------------------------------------------------------------------ modules
+class _ConvBase(nn.Module):
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, dimension=None, **_unused):
+        super().__init__()
+        if dimension != 3:
+            raise ValueError("lidog_amd implements the 3-D operators of the LiDOG hot path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation = int(kernel_size), int(stride), int(dilation)
+        self.dimension = dimension
+        self.kernel_volume = self.kernel_size ** 3
+        shape = (self.kernel_volume, in_channels, out_channels) if self.kernel_volume > 1 else \
+            (in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = (self.out_channels if self.transposed else self.in_channels) * self.kernel_volume
+        stdv = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def forward(self, x):
+        cm, s_in = x.coordinate_manager, x.coordinate_map_key
+        if self.kernel_volume == 1 and self.stride == 1:
+            m, s_out, swap, single_out, single_in = cm.identity_map(x.F.shape[0]), s_in, False, True, True
+        elif not self.transposed:
+            s_out = s_in * self.stride
+            m = cm.kernel_map(s_in, s_out, self.kernel_size, self.dilation)
+            swap, single_out = False, False
+            single_in = self.stride == self.kernel_size and self.stride > 1  # non-overlapping windows
+        else:
+            if s_in % self.stride != 0 or (s_in // self.stride) not in cm.maps:
+                raise ValueError("transposed convolution must land on an existing finer coordinate map")
+            s_out = s_in // self.stride
+            m = cm.kernel_map(s_out, s_in, self.kernel_size, self.dilation)
+            swap, single_in = True, False
+            single_out = self.stride == self.kernel_size and self.stride > 1
+        out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in)
+        return SparseTensor(out, coordinate_manager=cm, coordinate_map_key=s_out)
+
+
+class MinkowskiConvolution(_ConvBase):
+    transposed = False
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    transposed = True
+
+
+class MinkowskiBatchNorm(nn.Module):
+    _group = None
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, x, relu=False, residual=None):
+        res = residual.F if residual is not None else None
+        return x._like(batch_norm(x.F, self.bn, 1, relu, res, self._sync_group()))
+
+    def _sync_group(self):
+        return None
+
+
+class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
+    """Statistics all-reduced over the process group (RCCL); parameter names unchanged so checkpoints
+    interchange with the unsynchronised model (train_lidog.py:228, eval_target.py:153)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True,
+                 process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+
+    def _sync_group(self):
+        import torch.distributed as dist
+        if not (self.training and dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        return self.process_group if self.process_group is not None else dist.group.WORLD
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        out = module
+        if isinstance(module, MinkowskiBatchNorm) and not isinstance(module, MinkowskiSyncBatchNorm):
+            out = cls(module.bn.num_features, module.bn.eps, module.bn.momentum, module.bn.affine,
+                      module.bn.track_running_stats, process_group)
+            out.bn = module.bn
+            out.training = module.training
+        for name, child in module.named_children():
+            if out is module or name != "bn":
+                out.add_module(name, cls.convert_sync_batchnorm(child, process_group))
+        return out
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        f = x.F
+        inplace = self.inplace and not (f.requires_grad and f.is_leaf)
+        return x._like(_ReLUFn.apply(f, inplace))
+
+
+def bn_relu(bn_module, x):
+    """BatchNorm + ReLU as one fused pass (used by lidog_amd.minkunet when the backend offers it)"""
+    return bn_module(x, relu=True)
+
+
+class MinkowskiDropout(nn.Module):
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.drop = nn.Dropout(p, inplace)
+
+    def forward(self, x):
+        return x._like(self.drop(x.F))
+
+
+# ------------------------------------------------------------------ utils
+def _fans(t):
+    if t.dim() == 2:
+        return t.size(0), t.size(1)
+    return t.size(1) * t.size(0), t.size(2) * t.size(0)
+
+
+def kaiming_normal_(tensor, a=0, mode="fan_in", nonlinearity="leaky_relu"):
+    fan_in, fan_out = _fans(tensor)
+    std = nn.init.calculate_gain(nonlinearity, a) / math.sqrt(fan_in if mode == "fan_in" else fan_out)
+    with torch.no_grad():
+        return tensor.normal_(0, std)
+
+
+def batched_coordinates(coords, dtype=torch.int32, device=None):
+    out = []
+    for b, c in enumerate(coords):
+        c = torch.as_tensor(c)
+        out.append(torch.cat([torch.full((c.shape[0], 1), b, dtype=c.dtype), c], dim=1))
+    return torch.cat(out, dim=0).to(dtype)
+
+
+class SparseCollation:
+    """ME.utils.SparseCollation (utils/collation/collation.py:309): batch index prepended as column 0."""
+
+    def __init__(self, limit_numpoints=-1, dtype=torch.int32, device=None):
+        self.dtype, self.device = dtype, device
+
+    def __call__(self, list_data):
+        coords, feats, labels = list(zip(*list_data))
+        return (batched_coordinates(coords, dtype=self.dtype),
+                torch.cat([torch.as_tensor(f) for f in feats], dim=0),
+                torch.cat([torch.as_tensor(l) for l in labels], dim=0))
+
+
+utils = types.ModuleType(__name__ + ".utils")
+utils.kaiming_normal_ = kaiming_normal_
+utils.SparseCollation = SparseCollation
+utils.batched_coordinates = batched_coordinates
+
+
+# ------------------------------------------------------------------ modules.resnet_block
+class BasicBlock(nn.Module):
+    """conv3-BN-ReLU-conv3-BN-(+residual)-ReLU; BN+ReLU and BN+add+ReLU run as single fused kernels."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=-1):
+        super().__init__()
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                          dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dilation=dilation,
+                                          dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = self.norm1(self.conv1(x), relu=True)
+        residual = x if self.downsample is None else self.downsample(x)
+        return self.norm2(self.conv2(out), relu=True, residual=residual)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("Bottleneck is imported but never instantiated by the LiDOG hot path")
+
+
+modules = types.ModuleType(__name__ + ".modules")
+resnet_block = types.ModuleType(__name__ + ".modules.resnet_block")
+resnet_block.BasicBlock = BasicBlock
+resnet_block.Bottleneck = Bottleneck
+modules.resnet_block = resnet_block
+
+
+def install_as_minkowski_engine():
+    me = sys.modules[__name__]
+    sys.modules["MinkowskiEngine"] = me
+    sys.modules["MinkowskiEngine.utils"] = utils
+    sys.modules["MinkowskiEngine.modules"] = modules
+    sys.modules["MinkowskiEngine.modules.resnet_block"] = resnet_block
+    return me

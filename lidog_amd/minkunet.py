@@ -29,6 +29,7 @@ BEV_LEVEL_CHANNELS = {"block8": 96, "block7": 96, "block6": 128, "bottle": 256}
 
 def make_models(ME, Encoder2D=None, sparse2super=None):
     BasicBlock = ME.modules.resnet_block.BasicBlock
+    _fused = getattr(ME, "bn_relu", None)  # optional backend fast path: BN + ReLU in one kernel
 
     class _Trunk(nn.Module):
         BLOCK = BasicBlock
@@ -79,13 +80,16 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
                     nn.init.constant_(m.bn.weight, 1)
                     nn.init.constant_(m.bn.bias, 0)
 
+        def _bn_relu(self, bn, x):
+            return _fused(bn, x) if _fused is not None else self.relu(bn(x))
+
         def _trunk_forward(self, x):
             """returns (out_block8, out_bottle, {level: tensor})"""
-            out = self.relu(self.bn0(self.conv0p1s1(x)))
+            out = self._bn_relu(self.bn0, self.conv0p1s1(x))
             skips = [out]
             for i, s in _ENC:
                 out = getattr(self, f"conv{i}p{s}s2")(out)
-                out = self.relu(getattr(self, f"bn{i}")(out))
+                out = self._bn_relu(getattr(self, f"bn{i}"), out)
                 out = getattr(self, f"block{i}")(out)
                 skips.append(out)
             bottle = skips.pop()
@@ -93,7 +97,7 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
             names = ["bottle", "block6", "block7", "block8"]
             for (j, s), name in zip(_DEC, names):
                 out = getattr(self, f"convtr{j}p{s}s2")(out)
-                out = self.relu(getattr(self, f"bntr{j}")(out))
+                out = self._bn_relu(getattr(self, f"bntr{j}"), out)
                 out = ME.cat(out, skips.pop())
                 out = getattr(self, f"block{j + 1}")(out)
                 levels[name] = out

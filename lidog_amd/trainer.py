@@ -1,0 +1,202 @@
+"""Training step of LiDOG on the GPU: loss composition, Adam on a flat HBM buffer, RCCL data parallelism.
+
+Restates what the reference gets from pytorch-lightning (not installable here, and python that the GPU
+box never receives):
+  training_step        utils/pipelines/trainer_lighting_2d.py:141-201  (PLTTrainer2D)
+                       utils/pipelines/trainer_lighting.py:92-104      (PLTTrainer, source-only)
+  configure_optimizers utils/pipelines/trainer_lighting_2d.py:349-394  (Adam lr, weight_decay 1e-4)
+  DDP + SyncBN         train_lidog.py:227-231,286-289                   (strategy='ddp')
+
+One process per GPU; gradients live in ONE contiguous fp32 buffer that is all-reduced over RCCL in
+a few large buckets launched as soon as their last gradient is produced (overlapping the rest of
+backward), then consumed by a single fused Adam kernel.
+"""
+import torch
+import torch.distributed as dist
+
+from . import me as ME
+from ._lib import call, ptr
+from .losses import DICELoss, SoftDICELoss
+
+
+class FlatParams:
+    """Re-homes every parameter (and its .grad) of `model` into two contiguous fp32 buffers."""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            self.offsets.append(off)
+            off += n
+        self.total = total
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad; point it back
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+
+class GradientBuckets:
+    """Bucketed all-reduce (sum) of the flat gradient buffer, overlapped with backward.
+
+    Parameters are registered in forward order, gradients arrive roughly in reverse, so buckets are
+    contiguous slices walked from the END of the buffer.  xGMI is point-to-point (7 links per GPU):
+    a few large messages (default 32 MiB) keep every link busy without paying per-message latency."""
+
+    def __init__(self, flat, group=None, bucket_bytes=32 << 20):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.handles = []
+        self.bucket_of = {}
+        self.pending0 = []
+        self.slices = []
+        if self.world == 1:
+            return
+        cur_lo = cur_hi = flat.total
+        count = 0
+        members = []
+        for p, off in reversed(list(zip(flat.params, flat.offsets))):
+            members.append(p)
+            cur_lo = off
+            count += 1
+            if (cur_hi - cur_lo) * 4 >= bucket_bytes:
+                self._close(members, cur_lo, cur_hi, count)
+                members, count, cur_hi = [], 0, cur_lo
+        if members:
+            self._close(members, cur_lo, cur_hi, count)
+        self.pending = list(self.pending0)
+        for p in flat.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _close(self, members, lo, hi, count):
+        b = len(self.slices)
+        self.slices.append((lo, hi))
+        self.pending0.append(count)
+        for p in members:
+            self.bucket_of[id(p)] = b
+
+    def _hook(self, p):
+        b = self.bucket_of[id(p)]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            lo, hi = self.slices[b]
+            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+
+    def finish(self):
+        """wait for every bucket; buckets whose hooks did not all fire (unused parameters) are reduced now"""
+        if self.world == 1:
+            return
+        for b, left in enumerate(self.pending):
+            if left > 0:
+                lo, hi = self.slices[b]
+                self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.pending = list(self.pending0)
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay) semantics, one fused HIP kernel
+    over the flat buffer (csrc/conv2d.hip:k_adam); `grad_scale` folds the 1/world_size of DDP averaging."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, group=None,
+                 bucket_bytes=32 << 20):
+        self.flat = FlatParams(model)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(self.flat.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat)
+        self.steps = 0
+        self.buckets = GradientBuckets(self.flat, group, bucket_bytes)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self):
+        self.buckets.finish()
+        self.steps += 1
+        scale = 1.0 / self.buckets.world
+        call("lidog_adam_step", ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+             self.flat.total, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+             float(self.weight_decay), self.steps, float(scale))
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "steps": self.steps, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.steps, self.lr = sd["steps"], sd["lr"]
+
+
+class LiDOGStep:
+    """PLTTrainer2D.training_step without the host round trips (coords / logits stay in HBM)."""
+
+    def __init__(self, model, optimizer, source_weights=(0.5, 0.5), warmup_epochs=0, num_classes=7, ignore_label=-1):
+        self.model, self.opt = model, optimizer
+        self.w, self.warmup, self.nc = source_weights, warmup_epochs, num_classes
+        self.sem_criterion = SoftDICELoss(ignore_label=ignore_label)
+        self.bev_criterion = DICELoss(ignore_label=ignore_label)
+
+    def forward_loss(self, batch, epoch=0):
+        coords = batch["coords_int"] if "coords_int" in batch else batch["source_coordinates0"].int()
+        st = ME.SparseTensor(coordinates=coords, features=batch["source_features0"])
+        sem, bev = self.model(st, is_train=True)
+        bev_loss = 0.0
+        for key, lab in batch["source_bev_labels0"].items():
+            # NCHW logits through .view(-1, C): reproduces trainer_lighting_2d.py:181-182 literally
+            bev_loss = bev_loss + self.bev_criterion(bev[key].view(-1, self.nc), lab.view(-1)) / len(bev)
+        if epoch >= self.warmup:
+            sem_loss = self.sem_criterion(sem.F, batch["source_sem_labels0"].long())
+            total = self.w[0] * sem_loss + self.w[1] * bev_loss
+        else:
+            sem_loss = torch.zeros((), device=sem.F.device)
+            total = bev_loss
+        return total, sem_loss, bev_loss, sem
+
+    def training_step(self, batch, epoch=0):
+        total, sem_loss, bev_loss, _ = self.forward_loss(batch, epoch)
+        self.opt.zero_grad()
+        total.backward()
+        self.opt.step()
+        return {"loss": total.detach(), "sem_loss": sem_loss.detach(), "bev_loss": bev_loss.detach()}
+
+
+class SourceStep:
+    """PLTTrainer.training_step (train_source.py / Mix3D): MinkUNet34, SoftDICE only."""
+
+    def __init__(self, model, optimizer, ignore_label=-1):
+        self.model, self.opt = model, optimizer
+        self.criterion = SoftDICELoss(ignore_label=ignore_label)
+
+    def training_step(self, batch, epoch=0):
+        coords = batch["coords_int"] if "coords_int" in batch else batch["source_coordinates0"].int()
+        st = ME.SparseTensor(coordinates=coords, features=batch["source_features0"])
+        out = self.model(st, is_seg=True)
+        loss = self.criterion(out.F, batch["source_sem_labels0"].long())
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return {"loss": loss.detach()}
+
+
+def setup_data_parallel(model):
+    """train_lidog.py:227-231: SyncBatchNorm conversion of the sparse BNs when world_size > 1 (the two
+    BatchNorm2d of Encoder2D stay per-rank, as in the reference)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+    return model
+
+
+def shard_indices(n, rank, world):
+    """DistributedSampler-style rank-strided indices (what Lightning injects under strategy='ddp')"""
+    return list(range(rank, n - n % world if n >= world else n, world))

@@ -220,8 +220,14 @@ class _ConvBase(nn.Module):
         cm = x.coordinate_manager
         s_in = x.coordinate_map_key
         if self.kernel_volume == 1 and self.stride == 1:
-            out = x.F @ self.kernel
             s_out = s_in
+            if _MODE == "exact":  # same fmaf chain as every other kernel size (K = 1, in row == out row)
+                n = x.F.shape[0]
+                rows = torch.arange(n, dtype=torch.int32)
+                out = _SparseConvFn.apply(x.F, self.kernel.view(1, self.in_channels, self.out_channels),
+                                          torch.tensor([0, n], dtype=torch.int64), rows, rows, n)
+            else:
+                out = x.F @ self.kernel
         elif not self.transposed:
             s_out = s_in * self.stride
             k_off, pin, pout, _ = cm.kernel_map(s_in, s_out, self.kernel_size, self.dilation)

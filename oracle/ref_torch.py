@@ -30,6 +30,9 @@ def bev_pixels_ref(coords_xyz, bound, voxel=0.05):
     H = torch.tensor((hi - lo) / voxel).int()
     px = torch.floor((xyz[:, 0] - lo) / voxel).long()
     py = torch.floor(H - (xyz[:, 1] - lo) / voxel).long() - 1
+    # a negative index wraps in `dense[py, px] = feats` (float32 rounding gives py = -1 just inside the bound)
+    py = torch.where(py < 0, py + int(H), py)
+    px = torch.where(px < 0, px + int(H), px)
     return inb, px, py
 
 

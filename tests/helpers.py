@@ -28,7 +28,7 @@ def seeded_state_dict(model, seed=0):
         elif name.endswith("running_var"):
             v = torch.rand(t.shape, generator=g) + 0.5
         elif t.dim() == 1 and name.endswith("weight"):
-            v = torch.rand(t.shape, generator=g) + 0.5
+            v = torch.rand(t.shape, generator=g) * 0.6 + 0.4   # BN gains < 1 keep the residual stack O(1)
         elif name.endswith("bias"):
             v = torch.randn(t.shape, generator=g) * 0.1
         else:
@@ -39,6 +39,8 @@ def seeded_state_dict(model, seed=0):
             else:                 # Conv2d [Cout,Cin,kh,kw]
                 fan = t.shape[1] * t.shape[2] * t.shape[3]
             v = torch.randn(t.shape, generator=g) * math.sqrt(2.0 / fan)
+            if name == "final.kernel":
+                v = v * 0.25                                   # logits O(1): 1e-4 absolute is a real bar
         out[name] = v.to(t.dtype)
     return out
 

@@ -1,0 +1,100 @@
+"""Full-model parity on the GPU: MinkUNet34BEV / MinkUNet34 through the HIP path against golden vectors
+produced by the REFERENCE's own model classes (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, seeded_state_dict, sha_triples
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha_coords(t):
+    import hashlib
+    return hashlib.sha1(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+
+
+def test_minkunet34bev_matches_reference_golden():
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd.losses import SoftDICELoss, DICELoss
+    from lidog_amd.trainer import FlatAdam
+    g5 = np.load(f"{GOLDEN}/g5_minkunet34bev.npz")
+    C = torch.from_numpy(g5["coords"]).cuda()
+    labels = torch.from_numpy(g5["labels"]).cuda()
+    bev_labels = torch.from_numpy(g5["bev_labels"]).cuda()
+    model = lidog_amd.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5,
+                                    decoder_2d_level=["block8"], mapping_bound_2d=5.0)
+    assert list(model.state_dict().keys()) == list(g5["keys"]), "state_dict keys differ from the reference model"
+    model.load_state_dict(seeded_state_dict(model, seed=5))
+    model.cuda().train()
+    opt = FlatAdam(model, lr=1e-3, weight_decay=1e-4)
+    sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
+    feats = torch.ones((C.shape[0], 1), device="cuda")
+    losses = []
+    for step in range(3):
+        st = ME.SparseTensor(coordinates=C, features=feats)
+        sem, bev = model(st, is_train=True)
+        l_bev = bev_c(bev["block8"].view(-1, 7), bev_labels.view(-1))
+        l_sem = sem_c(sem.F, labels)
+        total = 0.5 * l_sem + 0.5 * l_bev
+        opt.zero_grad()
+        total.backward()
+        if step == 0:
+            cm = st.coordinate_manager
+            # voxel indices and kernel maps: bit-exact
+            assert [cm.maps[s].n for s in (1, 2, 4, 8, 16)] == g5["n_vox"].tolist()
+            for s in (2, 4, 8, 16):
+                assert _sha_coords(cm.maps[s].coords) == str(g5[f"coords_s{s}_sha1"])
+            for (s_in, s_out, k, d), km in cm.kmaps.items():
+                ref = g5[f"kmap_{s_in}_{s_out}_{k}"]
+                assert km.P == int(ref[1])
+                assert sha_triples(km.k_off_host, km.pair_in.cpu().numpy(), km.pair_out.cpu().numpy()) == str(ref[0])
+            assert len(cm.kmaps) == 10
+            # per-point logits within 1e-4 (north_star bar)
+            d = (sem.F.detach().cpu() - torch.from_numpy(g5["logits"])).abs().max().item()
+            assert d <= 1e-4, f"per-point logits differ by {d}"
+            d2 = (bev["block8"].detach().cpu() - torch.from_numpy(g5["bev_logits"])).abs().max().item()
+            assert d2 <= 1e-4, f"BEV logits differ by {d2}"
+            for n, p in model.named_parameters():
+                ref = float(g5[f"gnorm/{n}"])
+                assert abs(float(p.grad.norm()) - ref) <= 2e-3 * ref + 1e-7, (n, float(p.grad.norm()), ref)
+            for n in ("final.kernel", "final.bias", "conv0p1s1.kernel", "bn0.bn.weight"):
+                got = dict(model.named_parameters())[n].grad.cpu()
+                ref = torch.from_numpy(g5[f"grad/{n}"])
+                assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-7, n
+            torch.testing.assert_close(model.bn0.bn.running_mean.cpu(), torch.from_numpy(g5["bn0_running_mean"]),
+                                       rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(model.bn0.bn.running_var.cpu(), torch.from_numpy(g5["bn0_running_var"]),
+                                       rtol=1e-5, atol=1e-6)
+        losses.append([float(l_sem), float(l_bev), float(total)])
+        opt.step()
+    ref_losses = g5["losses"]
+    assert np.abs(np.array(losses) - ref_losses).max() <= 2e-4, (losses, ref_losses.tolist())
+    model.eval()
+    with torch.no_grad():
+        sem, none = model(ME.SparseTensor(coordinates=C, features=feats), is_train=False)
+    assert none is None
+    d = (sem.F.cpu() - torch.from_numpy(g5["eval_logits_after3"])).abs().max().item()
+    assert d <= 2e-3, f"eval logits after 3 Adam steps differ by {d}"
+
+
+def test_minkunet34_matches_reference_golden():
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd.losses import SoftDICELoss
+    g6 = np.load(f"{GOLDEN}/g6_minkunet34.npz")
+    C = torch.from_numpy(g6["coords"]).cuda()
+    labels = torch.from_numpy(g6["labels"]).cuda()
+    model = lidog_amd.MinkUNet34(in_channels=1, out_channels=7, D=3)
+    assert list(model.state_dict().keys()) == list(g6["keys"])
+    model.load_state_dict(seeded_state_dict(model, seed=7))
+    model.cuda().train()
+    sem = model(ME.SparseTensor(coordinates=C, features=torch.ones((C.shape[0], 1), device="cuda")), is_seg=True)
+    loss = SoftDICELoss(ignore_label=-1)(sem.F, labels)
+    loss.backward()
+    assert (sem.F.detach().cpu() - torch.from_numpy(g6["logits"])).abs().max().item() <= 1e-4
+    assert abs(float(loss) - float(g6["loss"])) <= 1e-5
+    for n, p in model.named_parameters():
+        ref = float(g6[f"gnorm/{n}"])
+        assert abs(float(p.grad.norm()) - ref) <= 2e-3 * ref + 1e-7, n

@@ -1,0 +1,197 @@
+"""GPU parity of every HIP operator against the CPU oracle (through the C ABI via lidog_amd.me)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from helpers import GOLDEN, small_batch, sha_triples
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_coords(seed, n=6000, extent=40, batches=2, dup=False):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.randint(-extent, extent, (n, 3), generator=g, dtype=torch.int32)
+    c[:, 2] = torch.randint(-6, 6, (n,), generator=g, dtype=torch.int32)
+    b = torch.randint(0, batches, (n, 1), generator=g, dtype=torch.int32)
+    c = torch.cat([b, c], dim=1)
+    if not dup:
+        c = torch.unique(c, dim=0)
+        c = c[torch.randperm(c.shape[0], generator=g)]
+    return c.contiguous()
+
+
+def _maps(coords):
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    so = OME.SparseTensor(coordinates=coords, features=torch.ones(coords.shape[0], 1))
+    sg = ME.SparseTensor(coordinates=coords.cuda(), features=torch.ones(coords.shape[0], 1).cuda())
+    return so, sg
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_stride_maps_bit_exact(seed):
+    coords = _rand_coords(seed)
+    so, sg = _maps(coords)
+    prev = 1
+    for s in (2, 4, 8, 16):
+        co = so.coordinate_manager.stride(prev, s)
+        cg = sg.coordinate_manager.stride(prev, s).coords
+        assert torch.equal(co, cg.cpu()), f"stride {s}: voxel rows differ"
+        prev = s
+
+
+def test_duplicates_first_occurrence():
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    coords = _rand_coords(3, n=5000, extent=12, dup=True)
+    feats = torch.arange(coords.shape[0], dtype=torch.float32).view(-1, 1)
+    so = OME.SparseTensor(coordinates=coords, features=feats)
+    sg = ME.SparseTensor(coordinates=coords.cuda(), features=feats.cuda())
+    assert so.C.shape[0] < coords.shape[0]
+    assert torch.equal(so.C, sg.C.cpu())
+    assert torch.equal(so.F, sg.F.cpu())
+
+
+@pytest.mark.parametrize("ks,s_in,s_out", [(3, 1, 1), (5, 1, 1), (2, 1, 2), (3, 2, 2), (2, 2, 4)])
+def test_kernel_maps_bit_exact(ks, s_in, s_out):
+    coords = _rand_coords(5)
+    so, sg = _maps(coords)
+    for cm in (so.coordinate_manager, sg.coordinate_manager):
+        if s_in > 1:
+            cm.stride(1, s_in)
+    k_off, pin, pout, nbr = so.coordinate_manager.kernel_map(s_in, s_out, ks)
+    km = sg.coordinate_manager.kernel_map(s_in, s_out, ks)
+    assert km.k_off_host == k_off.tolist()
+    # same pairs in the same order (k-major, ascending out row)
+    assert torch.equal(pin, km.pair_in.cpu()) and torch.equal(pout, km.pair_out.cpu())
+    assert torch.equal(nbr.t().contiguous(), km.nbr.cpu())
+    # position tables invert the pair lists
+    P = km.P
+    pos_out = km.pos_out.cpu()
+    ks_ = np.repeat(np.arange(km.K), np.diff(np.asarray(k_off)))
+    assert np.array_equal(pos_out[ks_, pout.numpy()].numpy(), np.arange(P))
+    pos_in = km.pos_in.cpu()
+    assert np.array_equal(pos_in[ks_, pin.numpy()].numpy(), np.arange(P))
+    assert int((pos_out >= 0).sum()) == P and int((pos_in >= 0).sum()) == P
+
+
+CONV_CASES = [
+    # Cin, Cout, ksize, stride, transposed, bias
+    (1, 32, 5, 1, False, False),
+    (32, 32, 3, 1, False, False),
+    (32, 64, 3, 1, False, False),
+    (96, 96, 3, 1, False, False),
+    (128, 96, 3, 1, False, False),
+    (384, 256, 3, 1, False, False),
+    (64, 64, 2, 2, False, False),
+    (256, 128, 2, 2, True, False),
+    (96, 7, 1, 1, False, True),
+    (192, 128, 1, 1, False, False),
+    (20, 12, 3, 1, False, True),   # generic fallback kernels
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,ks,stride,transposed,bias", CONV_CASES)
+def test_sparse_conv_fwd_bwd(Cin, Cout, ks, stride, transposed, bias):
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    OME.set_mode("exact")
+    coords = _rand_coords(7, n=3000, extent=16)
+    so, sg = _maps(coords)
+    if transposed:
+        so.coordinate_manager.stride(1, 2)
+        sg.coordinate_manager.stride(1, 2)
+        n_in = so.coordinate_manager.maps[2].shape[0]
+        key = 2
+    else:
+        n_in, key = coords.shape[0], 1
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(n_in, Cin, generator=g)
+    cls = "MinkowskiConvolutionTranspose" if transposed else "MinkowskiConvolution"
+    co = getattr(OME, cls)(Cin, Cout, kernel_size=ks, stride=stride, bias=bias, dimension=3)
+    cg = getattr(ME, cls)(Cin, Cout, kernel_size=ks, stride=stride, bias=bias, dimension=3).cuda()
+    cg.load_state_dict(co.state_dict())
+    xo = x.clone().requires_grad_(True)
+    xg = x.clone().cuda().requires_grad_(True)
+    yo = co(OME.SparseTensor(xo, coordinate_manager=so.coordinate_manager, coordinate_map_key=key))
+    yg = cg(ME.SparseTensor(xg, coordinate_manager=sg.coordinate_manager, coordinate_map_key=key))
+    assert yo.coordinate_map_key == yg.coordinate_map_key
+    # forward: identical fmaf chains and identical offset order -> bit-exact
+    assert torch.equal(yo.F.detach(), yg.F.detach().cpu()), (yo.F.detach() - yg.F.detach().cpu()).abs().max()
+    gy = torch.randn(yo.F.shape, generator=g)
+    yo.F.backward(gy)
+    yg.F.backward(gy.cuda())
+    assert torch.equal(xo.grad, xg.grad.cpu()), (xo.grad - xg.grad.cpu()).abs().max()
+    scale = co.kernel.grad.abs().max().item() + 1e-6
+    assert (co.kernel.grad - cg.kernel.grad.cpu()).abs().max().item() <= 2e-5 * scale
+    if bias:
+        torch.testing.assert_close(co.bias.grad, cg.bias.grad.cpu(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,relu,res", [(32, False, False), (96, True, False), (256, True, True), (7, True, True)])
+def test_batchnorm_rows(C, relu, res):
+    import lidog_amd.me as ME
+    g = torch.Generator().manual_seed(C)
+    n = 5003
+    x = torch.randn(n, C, generator=g) * 2 + 0.5
+    r = torch.randn(n, C, generator=g)
+    bn_ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5, generator=g)
+        bn_ref.bias.normal_(0, 0.2, generator=g)
+    mod = ME.MinkowskiBatchNorm(C).cuda()
+    mod.bn.load_state_dict(bn_ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True)
+    y = bn_ref(xr)
+    if res:
+        y = y + rr
+    if relu:
+        y = torch.relu(y)
+    xg = x.clone().cuda().requires_grad_(True)
+    rg = r.clone().cuda().requires_grad_(True)
+    yg = ME.batch_norm(xg, mod.bn, 1, relu, rg if res else None)
+    torch.testing.assert_close(yg.cpu(), y, rtol=1e-5, atol=2e-6)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    yg.backward(gy.cuda())
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(mod.bn.weight.grad.cpu(), bn_ref.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(mod.bn.bias.grad.cpu(), bn_ref.bias.grad, rtol=1e-4, atol=1e-4)
+    if res:
+        torch.testing.assert_close(rg.grad.cpu(), rr.grad, rtol=0, atol=0)
+    torch.testing.assert_close(mod.bn.running_mean.cpu(), bn_ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mod.bn.running_var.cpu(), bn_ref.running_var, rtol=1e-5, atol=1e-6)
+    # eval mode uses the running statistics
+    bn_ref.eval(), mod.eval()
+    torch.testing.assert_close(ME.batch_norm(x.cuda(), mod.bn, 1, False, None).cpu(), bn_ref(x), rtol=1e-5, atol=2e-6)
+
+
+def test_relu_add_cat():
+    import lidog_amd.me as ME
+    coords = _rand_coords(11, n=1000)
+    x = torch.randn(coords.shape[0], 24)
+    a = ME.SparseTensor(coordinates=coords.cuda(), features=x.cuda().requires_grad_(True))
+    b = ME.SparseTensor(x.cuda() * 2, coordinate_manager=a.coordinate_manager, coordinate_map_key=1)
+    c = ME.cat(a, b)
+    assert c.F.shape[1] == 48
+    r = ME.MinkowskiReLU(inplace=True)(a)
+    assert torch.equal(r.F.cpu(), torch.relu(x))
+    s = a + b
+    assert torch.equal(s.F.cpu(), x + 2 * x)
+    s.F.sum().backward()
+    with pytest.raises(ValueError):
+        other = ME.SparseTensor(coordinates=coords.cuda(), features=x.cuda())
+        ME.cat(a, other)
+    with pytest.raises(ValueError):
+        ME.SparseTensor(coordinates=coords.long().cuda(), features=x.cuda())
+    with pytest.raises(RuntimeError):
+        ME.SparseTensor(coordinates=coords, features=x)  # CPU tensors: no CPU path
+
+
+def test_coordinate_range_checked():
+    import lidog_amd.me as ME
+    coords = torch.tensor([[0, 0, 0, 0], [0, 70000, 0, 0]], dtype=torch.int32).cuda()
+    with pytest.raises(ValueError):
+        ME.SparseTensor(coordinates=coords, features=torch.ones(2, 1).cuda())
