@@ -40,17 +40,31 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
         for (int j = 0; j < 4; ++j) { m[j] = mean[c4 * 4 + j]; is[j] = invstd[c4 * 4 + j]; }
     }
     if (active) {
-        for (int64_t row = (int64_t)blockIdx.x * RB + r; row < n; row += (int64_t)gridDim.x * RB) {
-            float4 v = x[row * C4 + c4];
-            float4 g = make_float4(0, 0, 0, 0), y = make_float4(1, 1, 1, 1);
-            if (MODE == 1) {
-                g = dy[row * C4 + c4];
-                if (ry) y = ry[row * C4 + c4];
+        const int64_t step = (int64_t)gridDim.x * RB;
+        // 4 independent rows in flight per lane: the pass is a pure HBM/L2 stream
+        for (int64_t row0 = (int64_t)blockIdx.x * RB + r; row0 < n; row0 += 4 * step) {
+            float4 v[4], g[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int64_t row = row0 + u * step;
+                bool ok = row < n;
+                v[u] = ok ? x[row * C4 + c4] : make_float4(0, 0, 0, 0);
+                g[u] = make_float4(0, 0, 0, 0);
+                y[u] = make_float4(1, 1, 1, 1);
+                if (MODE == 1 && ok) {
+                    g[u] = dy[row * C4 + c4];
+                    if (ry) y[u] = ry[row * C4 + c4];
+                }
             }
-            red_terms<MODE>(v.x, g.x, y.x, ry != nullptr, m[0], is[0], a[0], a[4]);
-            red_terms<MODE>(v.y, g.y, y.y, ry != nullptr, m[1], is[1], a[1], a[5]);
-            red_terms<MODE>(v.z, g.z, y.z, ry != nullptr, m[2], is[2], a[2], a[6]);
-            red_terms<MODE>(v.w, g.w, y.w, ry != nullptr, m[3], is[3], a[3], a[7]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (row0 + u * step < n) {
+                    red_terms<MODE>(v[u].x, g[u].x, y[u].x, ry != nullptr, m[0], is[0], a[0], a[4]);
+                    red_terms<MODE>(v[u].y, g[u].y, y[u].y, ry != nullptr, m[1], is[1], a[1], a[5]);
+                    red_terms<MODE>(v[u].z, g[u].z, y[u].z, ry != nullptr, m[2], is[2], a[2], a[6]);
+                    red_terms<MODE>(v[u].w, g[u].w, y[u].w, ry != nullptr, m[3], is[3], a[3], a[7]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -137,8 +151,10 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
     if (hw == 1) {
         if (C % 4 == 0 && C / 4 <= 256) {
             int C4 = C / 4, RB = 256 / C4;
-            int64_t nb = cdiv64(n, (int64_t)RB * 8);
-            if (nb > 2048) nb = 2048;
+            // 2 workgroups per CU: enough loads in flight to stream, few enough that the 2*C double atomics
+            // per workgroup (all on the same 2*C addresses) stay off the critical path
+            int64_t nb = cdiv64(n, (int64_t)RB * 16);
+            if (nb > 512) nb = 512;
             k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy,
                                                                 (const float4 *)ry, n, C4, mean, invstd, sums);
         } else {

@@ -277,29 +277,44 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A
         for (int j = 0; j < CN; ++j) acc[i][j] = 0.f;
 
     constexpr int AV = (WG_R * TM / 4 + 255) / 256, GV = (WG_R * TN / 4 + 255) / 256;
-    for (int64_t p = p0; p < p1; p += WG_R) {
-        __syncthreads();
+    // register-staged software pipeline: the gathered rows of chunk t+1 are in flight while chunk t is
+    // multiplied out of LDS (the index load -> row load chain is two dependent HBM/L2 round trips)
+    float4 ra[AV], rg[GV];
+    auto load_chunk = [&](int64_t p) {
 #pragma unroll
         for (int j = 0; j < AV; ++j) {
             int f = tid + 256 * j;
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < WG_R * TM / 4) {
                 int r = f / (TM / 4), c4 = f % (TM / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p + r < p1) v = *reinterpret_cast<const float4 *>(A + (size_t)pa[p + r] * Cin + ci0 + c4 * 4);
-                *reinterpret_cast<float4 *>(&As[r * TM + c4 * 4]) = v;
+                if (p + r < p1) ra[j] = *reinterpret_cast<const float4 *>(A + (size_t)pa[p + r] * Cin + ci0 + c4 * 4);
             }
         }
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
             int f = tid + 256 * j;
+            rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < WG_R * TN / 4) {
                 int r = f / (TN / 4), c4 = f % (TN / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p + r < p1) v = *reinterpret_cast<const float4 *>(G + (size_t)pg[p + r] * Cout + co0 + c4 * 4);
-                *reinterpret_cast<float4 *>(&Gs[r * TN + c4 * 4]) = v;
+                if (p + r < p1) rg[j] = *reinterpret_cast<const float4 *>(G + (size_t)pg[p + r] * Cout + co0 + c4 * 4);
             }
         }
+    };
+    if (p0 < p1) load_chunk(p0);
+    for (int64_t p = p0; p < p1; p += WG_R) {
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            int f = tid + 256 * j;
+            if (f < WG_R * TM / 4) *reinterpret_cast<float4 *>(&As[f * 4]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            int f = tid + 256 * j;
+            if (f < WG_R * TN / 4) *reinterpret_cast<float4 *>(&Gs[f * 4]) = rg[j];
+        }
+        __syncthreads();
+        if (p + WG_R < p1) load_chunk(p + WG_R);
 #pragma unroll 8
         for (int r = 0; r < WG_R; ++r) {
             float a[RM], g[CN];
@@ -349,6 +364,79 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_small(const float *__restri
     }
 }
 
+// Cin == 1 (the 5^3 stem, in_channels = 1): gW[k][c] = sum_p a[pa[p]] * G[pg[p]][c]; one G row (Cout floats)
+// per Cout consecutive lanes, 256 / Cout pairs in flight per sweep
+__global__ __launch_bounds__(256) void k_sconv_wgrad_cin1(const float *__restrict__ A,
+                                                          const int32_t *__restrict__ pa,
+                                                          const float *__restrict__ G,
+                                                          const int32_t *__restrict__ pg,
+                                                          const int64_t *__restrict__ k_off, int K, int Cout,
+                                                          int n_split, float *__restrict__ partial) {
+    __shared__ float red[256];
+    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
+    const int64_t per = (seg1 - seg0 + n_split - 1) / n_split;
+    const int64_t p0 = seg0 + (int64_t)split * per;
+    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    const int c = threadIdx.x % Cout, r = threadIdx.x / Cout, RL = 256 / Cout;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (r < RL) {
+        int64_t p = p0 + r;
+        for (; p + RL < p1; p += 2 * RL) {
+            float a0 = A[pa[p]], a1 = A[pa[p + RL]];
+            float g0 = G[(size_t)pg[p] * Cout + c], g1 = G[(size_t)pg[p + RL] * Cout + c];
+            acc0 = __builtin_fmaf(a0, g0, acc0);
+            acc1 = __builtin_fmaf(a1, g1, acc1);
+        }
+        if (p < p1) acc0 = __builtin_fmaf(A[pa[p]], G[(size_t)pg[p] * Cout + c], acc0);
+    }
+    red[threadIdx.x] = acc0 + acc1;
+    __syncthreads();
+    if (r == 0) {
+        float s = red[c];
+        for (int rr = 1; rr < RL; ++rr) s += red[rr * Cout + c];
+        partial[((size_t)split * K + k) * Cout + c] = s;
+    }
+}
+
+// Cout <= 8 (the 1x1 classifier, 96 -> 7): one lane per input channel, Cout accumulators per lane
+__global__ __launch_bounds__(256) void k_sconv_wgrad_cout8(const float *__restrict__ A,
+                                                           const int32_t *__restrict__ pa,
+                                                           const float *__restrict__ G,
+                                                           const int32_t *__restrict__ pg,
+                                                           const int64_t *__restrict__ k_off, int K, int Cin,
+                                                           int Cout, int n_split, float *__restrict__ partial) {
+    __shared__ float red[8 * 256];
+    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
+    const int64_t per = (seg1 - seg0 + n_split - 1) / n_split;
+    const int64_t p0 = seg0 + (int64_t)split * per;
+    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    const int ci = threadIdx.x % Cin, r = threadIdx.x / Cin, RL = 256 / Cin;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (r < RL) {
+        for (int64_t p = p0 + r; p < p1; p += RL) {
+            float a = A[(size_t)pa[p] * Cin + ci];
+            const float *g = G + (size_t)pg[p] * Cout;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < Cout) acc[j] = __builtin_fmaf(a, g[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] = acc[j];
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 0; j < Cout; ++j) {
+            float s = red[j * 256 + ci];
+            for (int rr = 1; rr < RL; ++rr) s += red[j * 256 + rr * Cin + ci];
+            partial[(((size_t)split * K + k) * Cin + ci) * Cout + j] = s;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_split_sum(const float *__restrict__ partial, int64_t n, int n_split,
                                                    float *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -393,6 +481,12 @@ extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const fl
             case 4: launch_wgrad_rm<4>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
             default: launch_wgrad_rm<2>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst);
         }
+    } else if (Cin == 1 && Cout <= 256) {
+        k_sconv_wgrad_cin1<<<dim3((unsigned)(K * n_split)), 256, 0, st>>>(A, pair_a, G, pair_g, k_off_dev, K, Cout,
+                                                                          n_split, dst);
+    } else if (Cout <= 8 && Cin <= 256) {
+        k_sconv_wgrad_cout8<<<dim3((unsigned)(K * n_split)), 256, 0, st>>>(A, pair_a, G, pair_g, k_off_dev, K, Cin,
+                                                                           Cout, n_split, dst);
     } else {
         int by = (Cin * Cout + 255) / 256;
         if (by > 64) by = 64;

@@ -273,8 +273,8 @@ def _wgrad_splits(K, Cin, Cout, P):
                 return t
         return c
     tiles = max(1, (Cin // tile(Cin)) * (Cout // tile(Cout)))
-    s = max(1, -(-1024 // (K * tiles)))
-    s = min(s, 64, max(1, P // (K * 256)))
+    s = max(1, -(-1024 // (K * tiles)))          # about 4 workgroups per CU
+    s = min(s, 256, max(1, P // (K * 256)))      # but at least 256 pairs per split
     return s
 
 

@@ -169,12 +169,18 @@ def g5_full_model():
     model = RefBEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"],
                    mapping_bound_2d=5.0)
     model.load_state_dict(seeded_state_dict(model, seed=5))
+    feats = torch.ones((N, 1))
+    out = {}
+    # validation path first (is_train=False: no BEV head, seeded running statistics; minkunet_bev.py:376-393)
+    model.eval()
+    with torch.no_grad():
+        sem0, none0 = model(ME.SparseTensor(coordinates=C, features=feats), is_train=False)
+    assert none0 is None
+    out["eval_logits_initial"] = sem0.F.numpy().copy()
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
-    feats = torch.ones((N, 1))
     losses = []
-    out = {}
     for step in range(3):
         st = ME.SparseTensor(coordinates=C, features=feats)
         sem, bev = model(st, is_train=True)
