@@ -260,3 +260,22 @@ def test_shared_library_exports_every_declared_symbol():
     assert lib.lidog_abi_version() == 1
     lib.lidog_hash_capacity.restype = ctypes.c_int64
     assert lib.lidog_hash_capacity(ctypes.c_int64(1000)) == 2048
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/utils/models"), reason="reference only exists in the build container")
+def test_reference_model_file_builds_on_product_api():
+    """INTEGRATION.md route 1: the reference's own minkunet_bev.py constructs on top of lidog_amd.me
+    (run in a subprocess so the alias does not leak into this interpreter)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.dont_write_bytecode = True; sys.path.insert(0, %r); sys.path.insert(1, '/root/reference');"
+        "import lidog_amd.me as ME; ME.install_as_minkowski_engine();"
+        "from utils.models.minkunet_bev import MinkUNet34BEV as Ref; import lidog_amd;"
+        "r = Ref(in_channels=1, out_channels=7, D=3); m = lidog_amd.MinkUNet34BEV(1, 7, 3);"
+        "assert list(r.state_dict().keys()) == list(m.state_dict().keys());"
+        "assert all(a.shape == b.shape for a, b in zip(r.state_dict().values(), m.state_dict().values()));"
+        "print('ok')" % REPO)
+    out = subprocess.run([sys.executable, "-B", "-c", code], capture_output=True, text=True,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
