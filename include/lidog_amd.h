@@ -99,6 +99,14 @@ int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, con
                       const int64_t *k_off_dev, int32_t K, int32_t Cin, int32_t Cout, int32_t n_split,
                       float *partial, float *gW, void *stream);
 
+/* slabs of K*Cin*Cout floats that `partial` must hold for lidog_sconv_wgrad with this n_split (>= n_split) */
+int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_split);
+
+/* Arithmetic core of lidog_sconv_gemm / lidog_sconv_wgrad: 1 = exact-f32 MFMA (default), 0 = vector FMA.
+ * Both produce bit-identical results (an f32 MFMA is a k-ordered fmaf chain); kept selectable for A/B. */
+int lidog_set_sparse_core(int32_t core);
+int lidog_get_sparse_core(void);
+
 /* Wt[k][co][ci] = W[k][ci][co] */
 int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout, float *Wt, void *stream);
 

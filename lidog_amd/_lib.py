@@ -23,6 +23,9 @@ SIGNATURES = {
     "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
+    "lidog_set_sparse_core": [_i32],
+    "lidog_get_sparse_core": [],
     "lidog_transpose_kernel": [_p, _i32, _i32, _i32, _p, _p],
     "lidog_bn_stats": [_p, _i64, _i32, _i64, _p, _p],
     "lidog_bn_finalize": [_p, _d, _i32, _f, _f, _p, _p, _p, _p, _p],

@@ -3,6 +3,16 @@
 // weight gradient by split reduction over pairs.  CPU restatement: oracle/me_oracle.c
 // (orc_conv_fwd / orc_conv_bwd_data / orc_conv_bwd_weight).
 #include "common.h"
+#include "sconv_mfma.h"
+
+// 1 = exact-f32 MFMA cores (default), 0 = vector-FMA cores; identical results, see sconv_mfma.hip
+static int g_sparse_core = 1;
+extern "C" int lidog_set_sparse_core(int32_t core) {
+    LIDOG_REQUIRE(core == 0 || core == 1, "sparse core must be 0 (vector FMA) or 1 (MFMA f32)");
+    g_sparse_core = core;
+    return 0;
+}
+extern "C" int lidog_get_sparse_core(void) { return g_sparse_core; }
 
 // ------------------------------------------------------------------ gathered GEMM
 // Tile: 128 pair-rows x (16*CN) columns, BK = 32 input channels per step, 256 threads as 16 (ty) x 16 (tx).
@@ -52,8 +62,10 @@ __global__ __launch_bounds__(256) void k_sconv_gemm(const float *__restrict__ A,
             int f = tid + 256 * j;
             int r = f >> 3, q = f & 7;
             int src = s_src[r];
-            ra[j] = (src >= 0) ? *reinterpret_cast<const float4 *>(A + (size_t)src * Cin + kb + q * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional load + select (a branch around the load would serialise the gather)
+            float4 v = *reinterpret_cast<const float4 *>(A + (size_t)(src < 0 ? 0 : src) * Cin + kb + q * 4);
+            bool ok = src >= 0;
+            ra[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll
         for (int j = 0; j < BV; ++j) {
@@ -97,17 +109,20 @@ __global__ __launch_bounds__(256) void k_sconv_gemm(const float *__restrict__ A,
             for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const float4 *>(&As[(ty + 16 * i) * GM_SA + k4]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+                // column ownership is interleaved: vector v of this lane sits at column v*16*V + tx*V, so the
+                // 16 lanes of one row group read 16*V contiguous floats (no LDS bank conflict)
                 float b[CN];
-                if constexpr (CN % 4 == 0) {
+                constexpr int V = (CN % 4 == 0) ? 4 : 2;
+                if constexpr (V == 4) {
 #pragma unroll
                     for (int j = 0; j < CN; j += 4) {
-                        float4 v = *reinterpret_cast<const float4 *>(&Bs[(k4 + s) * TN + tx * CN + j]);
+                        float4 v = *reinterpret_cast<const float4 *>(&Bs[(k4 + s) * TN + j * 16 + tx * 4]);
                         b[j] = v.x; b[j + 1] = v.y; b[j + 2] = v.z; b[j + 3] = v.w;
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < CN; j += 2) {
-                        float2 v = *reinterpret_cast<const float2 *>(&Bs[(k4 + s) * TN + tx * CN + j]);
+                        float2 v = *reinterpret_cast<const float2 *>(&Bs[(k4 + s) * TN + j * 16 + tx * 2]);
                         b[j] = v.x; b[j + 1] = v.y;
                     }
                 }
@@ -121,18 +136,28 @@ __global__ __launch_bounds__(256) void k_sconv_gemm(const float *__restrict__ A,
         }
     }
 
-    // epilogue: one coalesced row segment per (row, tx)
+    // epilogue: per (row, vector) one coalesced segment of 16 lanes
+    constexpr int V = (CN % 4 == 0) ? 4 : 2;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         int r = ty + 16 * i;
         if (r < rows) {
             size_t dst = scatter ? (size_t)scatter[row0 + r] : (size_t)(row0 + r);
-            float *out = T + dst * Cout + col0 + tx * CN;
+            float *out = T + dst * Cout + col0;
 #pragma unroll
-            for (int j = 0; j < CN; j += 2) {
-                float2 v = make_float2(acc[i][j], acc[i][j + 1]);
-                if (bias) { v.x += bias[col0 + tx * CN + j]; v.y += bias[col0 + tx * CN + j + 1]; }
-                *reinterpret_cast<float2 *>(out + j) = v;
+            for (int j = 0; j < CN; j += V) {
+                int c = j * 16 + tx * V;
+                if constexpr (V == 4) {
+                    float4 v = make_float4(acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3]);
+                    if (bias) {
+                        v.x += bias[col0 + c]; v.y += bias[col0 + c + 1]; v.z += bias[col0 + c + 2]; v.w += bias[col0 + c + 3];
+                    }
+                    *reinterpret_cast<float4 *>(out + c) = v;
+                } else {
+                    float2 v = make_float2(acc[i][j], acc[i][j + 1]);
+                    if (bias) { v.x += bias[col0 + c]; v.y += bias[col0 + c + 1]; }
+                    *reinterpret_cast<float2 *>(out + c) = v;
+                }
             }
         }
     }
@@ -170,6 +195,11 @@ extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const flo
     hipStream_t st = (hipStream_t)stream;
     if (n_tiles == 0) return 0;
     LIDOG_REQUIRE(Cin > 0 && Cout > 0, "sconv_gemm: bad channel counts %d %d", Cin, Cout);
+    if (g_sparse_core == 1 && Cin % 32 == 0 && Cout % 32 == 0) {
+        lidog_launch_gemm_mfma(A, gather, B, bias, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, scatter, st);
+        LIDOG_LAUNCH_CHECK();
+        return 0;
+    }
     int cn = 0;
     if (Cin % GM_BK == 0) {
         if (Cout % 128 == 0) cn = 8;
@@ -281,23 +311,40 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A
     // multiplied out of LDS (the index load -> row load chain is two dependent HBM/L2 round trips)
     float4 ra[AV], rg[GV];
     auto load_chunk = [&](int64_t p) {
+        // Unconditional loads (clamped pair index, zero-select afterwards), indices first: a branch around a
+        // load makes hipcc wait vmcnt(0) per element and serialises the whole two-level gather.
+        int ia[AV], ig[GV];
 #pragma unroll
         for (int j = 0; j < AV; ++j) {
             int f = tid + 256 * j;
-            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < WG_R * TM / 4) {
-                int r = f / (TM / 4), c4 = f % (TM / 4);
-                if (p + r < p1) ra[j] = *reinterpret_cast<const float4 *>(A + (size_t)pa[p + r] * Cin + ci0 + c4 * 4);
-            }
+            f = f < WG_R * TM / 4 ? f : WG_R * TM / 4 - 1;
+            int64_t pr = p + f / (TM / 4);
+            ia[j] = pa[pr < p1 ? pr : p1 - 1];
         }
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
             int f = tid + 256 * j;
-            rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < WG_R * TN / 4) {
-                int r = f / (TN / 4), c4 = f % (TN / 4);
-                if (p + r < p1) rg[j] = *reinterpret_cast<const float4 *>(G + (size_t)pg[p + r] * Cout + co0 + c4 * 4);
-            }
+            f = f < WG_R * TN / 4 ? f : WG_R * TN / 4 - 1;
+            int64_t pr = p + f / (TN / 4);
+            ig[j] = pg[pr < p1 ? pr : p1 - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            int f = tid + 256 * j;
+            f = f < WG_R * TM / 4 ? f : WG_R * TM / 4 - 1;
+            int r = f / (TM / 4), c4 = f % (TM / 4);
+            float4 v = *reinterpret_cast<const float4 *>(A + (size_t)ia[j] * Cin + ci0 + c4 * 4);
+            bool ok = p + r < p1;
+            ra[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            int f = tid + 256 * j;
+            f = f < WG_R * TN / 4 ? f : WG_R * TN / 4 - 1;
+            int r = f / (TN / 4), c4 = f % (TN / 4);
+            float4 v = *reinterpret_cast<const float4 *>(G + (size_t)ig[j] * Cout + co0 + c4 * 4);
+            bool ok = p + r < p1;
+            rg[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     };
     if (p0 < p1) load_chunk(p0);
@@ -323,10 +370,18 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A
                 float2 v = *reinterpret_cast<const float2 *>(&As[r * TM + ty * RM + i]);
                 a[i] = v.x; a[i + 1] = v.y;
             }
+            if constexpr (CN % 4 == 0) {  // interleaved column ownership: conflict-free LDS reads (see k_sconv_gemm)
 #pragma unroll
-            for (int j = 0; j < CN; j += 2) {
-                float2 v = *reinterpret_cast<const float2 *>(&Gs[r * TN + tx * CN + j]);
-                g[j] = v.x; g[j + 1] = v.y;
+                for (int j = 0; j < CN; j += 4) {
+                    float4 v = *reinterpret_cast<const float4 *>(&Gs[r * TN + j * 16 + tx * 4]);
+                    g[j] = v.x; g[j + 1] = v.y; g[j + 2] = v.z; g[j + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CN; j += 2) {
+                    float2 v = *reinterpret_cast<const float2 *>(&Gs[r * TN + j * 16 + tx * 2]);
+                    g[j] = v.x; g[j + 1] = v.y;
+                }
             }
 #pragma unroll
             for (int i = 0; i < RM; ++i)
@@ -337,9 +392,15 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A
     float *dst = partial + ((size_t)split * K + k) * Cin * Cout;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
-        float *row = dst + (size_t)(ci0 + ty * RM + i) * Cout + co0 + tx * CN;
+        float *row = dst + (size_t)(ci0 + ty * RM + i) * Cout + co0;
+        constexpr int V = (CN % 4 == 0) ? 4 : 2;
 #pragma unroll
-        for (int j = 0; j < CN; j += 2) *reinterpret_cast<float2 *>(row + j) = make_float2(acc[i][j], acc[i][j + 1]);
+        for (int j = 0; j < CN; j += V) {
+            if constexpr (V == 4)
+                *reinterpret_cast<float4 *>(row + j * 16 + tx * 4) = make_float4(acc[i][j], acc[i][j + 1], acc[i][j + 2], acc[i][j + 3]);
+            else
+                *reinterpret_cast<float2 *>(row + j * 16 + tx * 2) = make_float2(acc[i][j], acc[i][j + 1]);
+        }
     }
 }
 
@@ -466,12 +527,29 @@ static void launch_wgrad_rm(int cn, dim3 grid, hipStream_t st, const float *A, c
     }
 }
 
+// number of [K,Cin,Cout] slabs the caller must provide in `partial` for a given split count
+extern "C" int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_split) {
+    if (g_sparse_core == 1 && pick_tile(Cin) && pick_tile(Cout)) return lidog_wgrad_mfma_slabs(Cin, Cout, n_split);
+    return n_split;
+}
+
 extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
                                  const int64_t *k_off_dev, int32_t K, int32_t Cin, int32_t Cout, int32_t n_split,
                                  float *partial, float *gW, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(n_split >= 1 && K >= 1, "sconv_wgrad: bad n_split/K");
     int rm = pick_tile(Cin), cn = pick_tile(Cout);
+    if (g_sparse_core == 1 && rm && cn) {
+        int slabs = lidog_wgrad_mfma_slabs(Cin, Cout, n_split);
+        LIDOG_REQUIRE(slabs == 1 || partial != nullptr, "sconv_wgrad: partial workspace needed for %d slabs", slabs);
+        lidog_launch_wgrad_mfma(A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, slabs == 1 ? gW : partial, st);
+        if (slabs > 1) {
+            int64_t n = (int64_t)K * Cin * Cout;
+            k_split_sum<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(partial, n, slabs, gW);
+        }
+        LIDOG_LAUNCH_CHECK();
+        return 0;
+    }
     float *dst = (n_split == 1) ? gW : partial;
     if (rm && cn) {
         dim3 grid((unsigned)(K * n_split), (unsigned)((Cin / (16 * rm)) * (Cout / (16 * cn))));

@@ -1,0 +1,338 @@
+// Exact-f32 matrix-core versions of the two sparse-convolution GEMMs (gathered GEMM and weight gradient).
+// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md, "FP32-input MFMA"),
+// so results are IDENTICAL to the vector-FMA kernels of sconv.hip and to oracle/me_oracle.c; what changes is
+// the operand traffic: one LDS dword per lane per MFMA instead of ~1 B of LDS per FMA, which is what caps the
+// vector kernels near 40 % of the (common) 157 TF/s fp32 roof.
+//
+// MFMA 32x32x2 lane maps: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
+// D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5) for accumulator register e.
+#include "common.h"
+#include "sconv_mfma.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MG_TM 128
+#define MG_BK 32
+#define MG_SA 33  // odd row stride: the 32 lanes of an A read (one row each) hit 32 different banks
+
+// ------------------------------------------------------------------ gathered GEMM
+// Tile 128 pair-rows x 32*NT columns; wave w owns rows [32w, 32w+32) and all NT column tiles.
+template <int NT>
+__global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict__ A,
+                                                         const int32_t *__restrict__ gather,
+                                                         const float *__restrict__ B,
+                                                         const float *__restrict__ bias,
+                                                         const int32_t *__restrict__ tile_k,
+                                                         const int32_t *__restrict__ tile_row0,
+                                                         const int32_t *__restrict__ tile_rows, int Cin, int Cout,
+                                                         float *__restrict__ T,
+                                                         const int32_t *__restrict__ scatter) {
+    constexpr int TN = 32 * NT;
+    constexpr int BV = (MG_BK * TN / 4) / 256;  // float4 of B per thread per chunk (1..4)
+    __shared__ float As[MG_TM * MG_SA];
+    __shared__ __attribute__((aligned(16))) float Bs[MG_BK * TN];
+    __shared__ int32_t s_src[MG_TM];
+    __shared__ int32_t s_dst[MG_TM];
+
+    const int tile = blockIdx.x;
+    const int k = tile_k[tile], row0 = tile_row0[tile], rows = tile_rows[tile];
+    const int col0 = blockIdx.y * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+
+    if (tid < MG_TM) {
+        int src = -1, dst = -1;
+        if (tid < rows) {
+            src = gather ? gather[row0 + tid] : (row0 + tid);
+            dst = scatter ? scatter[row0 + tid] : (row0 + tid);
+        }
+        s_src[tid] = src;
+        s_dst[tid] = dst;
+    }
+    __syncthreads();
+
+    const float *Bk = B + (size_t)k * Cin * Cout + col0;
+    // rb0..rb3 are separate named registers on purpose: as an array (float4 rb[BV]) hipcc keeps the B
+    // staging values in scratch memory for BV >= 2
+    float4 ra[4], rb0, rb1, rb2, rb3;
+    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define MG_LOADB(J, R)                                                                      \
+    if constexpr (BV > J) {                                                                 \
+        int f = tid + 256 * J;                                                              \
+        int kk = f / (TN / 4), c4 = f % (TN / 4);                                           \
+        R = *reinterpret_cast<const float4 *>(Bk + (size_t)(kb + kk) * Cout + c4 * 4);      \
+    }
+#define MG_STOREB(J, R) \
+    if constexpr (BV > J) *reinterpret_cast<float4 *>(&Bs[(tid + 256 * J) * 4]) = R;
+    auto load_chunk = [&](int kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int f = tid + 256 * j;
+            int r = f >> 3, q = f & 7;  // 8 lanes fetch one 128-B line of a gathered row
+            int src = s_src[r];
+            // unconditional load + select (a branch around the load would serialise the gather)
+            float4 v = *reinterpret_cast<const float4 *>(A + (size_t)(src < 0 ? 0 : src) * Cin + kb + q * 4);
+            bool ok = src >= 0;
+            ra[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+        MG_LOADB(0, rb0) MG_LOADB(1, rb1) MG_LOADB(2, rb2) MG_LOADB(3, rb3)
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int f = tid + 256 * j;
+            int r = f >> 3, q = f & 7;
+            const int o = r * MG_SA + q * 4;
+            As[o] = ra[j].x;
+            As[o + 1] = ra[j].y;
+            As[o + 2] = ra[j].z;
+            As[o + 3] = ra[j].w;
+        }
+        MG_STOREB(0, rb0) MG_STOREB(1, rb1) MG_STOREB(2, rb2) MG_STOREB(3, rb3)
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    load_chunk(0);
+    for (int kb = 0; kb < Cin; kb += MG_BK) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        // unconditional prefetch (the last iteration re-reads its own chunk): a branch around the staging
+        // registers sends them through scratch memory
+        load_chunk(kb + MG_BK < Cin ? kb + MG_BK : kb);
+        const float *arow = &As[(wave * 32 + li) * MG_SA + kh];
+        const float *bcol = &Bs[kh * TN + li];
+#pragma unroll
+        for (int k2 = 0; k2 < MG_BK / 2; ++k2) {
+            float a = arow[2 * k2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcol[2 * k2 * TN + 32 * t], acc[t], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        int dst = s_dst[r];
+        if (dst >= 0) {
+            float *out = T + (size_t)dst * Cout + col0 + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v = acc[t][e];
+                if (bias) v += bias[col0 + 32 * t + li];
+                out[32 * t] = v;
+            }
+        }
+    }
+}
+
+int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B, const float *bias,
+                           const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
+                           int Cin, int Cout, float *T, const int32_t *scatter, hipStream_t st) {
+    int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
+    dim3 grid((unsigned)n_tiles, (unsigned)(Cout / (32 * nt)));
+#define LAUNCH(NT_)                                                                                               \
+    k_sconv_gemm_mfma<NT_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, \
+                                                 scatter)
+    switch (nt) {
+        case 4: LAUNCH(4); break;
+        case 3: LAUNCH(3); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(1);
+    }
+#undef LAUNCH
+    return 0;
+}
+
+// ------------------------------------------------------------------ weight gradient
+// gW[k] tile (32 MT) x (32 NT) = sum over pairs of A_row^T (x) G_row.  Rows are the MFMA k dimension, taken
+// straight from the row-major LDS images (no transpose).  NW waves share the MT*NT MFMA tiles; when there
+// are fewer tiles than waves the waves form NGRP groups that each take every NGRP-th row pair and emit
+// their own partial slab.
+#define MW_R 32
+template <int MT, int NT, int NW, int NGRP>
+__global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__restrict__ A,
+                                                              const int32_t *__restrict__ pa,
+                                                              const float *__restrict__ G,
+                                                              const int32_t *__restrict__ pg,
+                                                              const int64_t *__restrict__ k_off, int K, int Cin,
+                                                              int Cout, int n_split, float *__restrict__ partial) {
+    constexpr int TM = 32 * MT, TN = 32 * NT, NTH = 64 * NW;
+    constexpr int TILES = MT * NT;
+    constexpr int WPG = NW / NGRP;            // waves per group
+    constexpr int TPW = (TILES + WPG - 1) / WPG;  // tiles per wave
+    __shared__ __attribute__((aligned(16))) float As[MW_R * TM];
+    __shared__ __attribute__((aligned(16))) float Gs[MW_R * TN];
+    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int tiles_n = Cout / TN;
+    const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int grp = wave / WPG, wig = wave % WPG;
+    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
+    const int64_t per = ((seg1 - seg0 + n_split - 1) / n_split + MW_R - 1) / MW_R * MW_R;
+    const int64_t p0 = seg0 + (int64_t)split * per;
+    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+
+    int a_off[TPW], g_off[TPW];
+    bool own[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        int tt = wig * TPW + t;  // tiles enumerated column-major: tt = nj * MT + mi
+        own[t] = tt < TILES;
+        int mi = own[t] ? tt % MT : 0, nj = own[t] ? tt / MT : 0;
+        a_off[t] = 32 * mi + li;
+        g_off[t] = 32 * nj + li;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    constexpr int AV = (MW_R * TM / 4 + NTH - 1) / NTH, GV = (MW_R * TN / 4 + NTH - 1) / NTH;
+    // Software pipeline, two levels deep: pair indices of chunk t+2 and gathered rows of chunk t+1 are in
+    // flight while chunk t is multiplied.  All loads are unconditional (clamped index, zero-select after):
+    // a branch around a load makes hipcc wait vmcnt(0) per element and serialises the two-level gather.
+    float4 ra[AV], rg[GV];
+    int ia[AV], ig[GV];
+    auto load_idx = [&](int64_t p) {
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            int f = tid + NTH * j;
+            f = f < MW_R * TM / 4 ? f : MW_R * TM / 4 - 1;
+            int64_t pr = p + f / (TM / 4);
+            ia[j] = pa[pr < p1 ? pr : p1 - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            int f = tid + NTH * j;
+            f = f < MW_R * TN / 4 ? f : MW_R * TN / 4 - 1;
+            int64_t pr = p + f / (TN / 4);
+            ig[j] = pg[pr < p1 ? pr : p1 - 1];
+        }
+    };
+    auto load_rows = [&](int64_t p) {
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            int f = tid + NTH * j;
+            f = f < MW_R * TM / 4 ? f : MW_R * TM / 4 - 1;
+            int r = f / (TM / 4), c4 = f % (TM / 4);
+            float4 v = *reinterpret_cast<const float4 *>(A + (size_t)ia[j] * Cin + ci0 + c4 * 4);
+            bool ok = p + r < p1;
+            ra[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            int f = tid + NTH * j;
+            f = f < MW_R * TN / 4 ? f : MW_R * TN / 4 - 1;
+            int r = f / (TN / 4), c4 = f % (TN / 4);
+            float4 v = *reinterpret_cast<const float4 *>(G + (size_t)ig[j] * Cout + co0 + c4 * 4);
+            bool ok = p + r < p1;
+            rg[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+    if (p0 < p1) {
+        load_idx(p0);
+        load_rows(p0);
+        load_idx(p0 + MW_R);
+    }
+    for (int64_t p = p0; p < p1; p += MW_R) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            int f = tid + NTH * j;
+            if (f < MW_R * TM / 4) *reinterpret_cast<float4 *>(&As[f * 4]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < GV; ++j) {
+            int f = tid + NTH * j;
+            if (f < MW_R * TN / 4) *reinterpret_cast<float4 *>(&Gs[f * 4]) = rg[j];
+        }
+        __syncthreads();
+        if (p + MW_R < p1) {
+            load_rows(p + MW_R);
+            load_idx(p + 2 * MW_R);
+        }
+        // compile-time trip count (the group only offsets the address) so the LDS reads of all steps can be
+        // issued ahead of the MFMA chain with counted lgkmcnt waits
+#pragma unroll
+        for (int q = 0; q < MW_R / 2 / NGRP; ++q) {
+            const int kk = 2 * (q * NGRP + grp) + kh;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk * TM + a_off[t]], Gs[kk * TN + g_off[t]], acc[t],
+                                                              0, 0, 0);
+        }
+    }
+    float *dst = partial + ((size_t)(split * NGRP + grp) * K + k) * Cin * Cout;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        if (!own[t]) continue;
+        int tt = wig * TPW + t;
+        int mi = tt % MT, nj = tt / MT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int ci = ci0 + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            dst[(size_t)ci * Cout + co0 + 32 * nj + li] = acc[t][e];
+        }
+    }
+}
+
+static int tile32(int C) { return (C % 128 == 0) ? 4 : (C % 96 == 0) ? 3 : (C % 64 == 0) ? 2 : 1; }
+
+// (NW, NGRP) per tile count: every wave gets the same number of MFMA tiles, or rows are split over groups
+static void wg_shape(int tiles, int *nw, int *ngrp) {
+    switch (tiles) {
+        case 1: *nw = 4; *ngrp = 4; break;
+        case 2: *nw = 4; *ngrp = 2; break;
+        case 3: case 6: case 9: *nw = 3; *ngrp = 1; break;
+        default: *nw = 4; *ngrp = 1;  // 4, 8, 12, 16
+    }
+}
+
+int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_split) {
+    int nw, ngrp;
+    wg_shape(tile32(Cin) * tile32(Cout), &nw, &ngrp);
+    return n_split * ngrp;
+}
+
+template <int MT, int NT, int NW, int NGRP>
+static void launch_wg(dim3 grid, hipStream_t st, const float *A, const int32_t *pa, const float *G, const int32_t *pg,
+                      const int64_t *k_off, int K, int Cin, int Cout, int n_split, float *partial) {
+    k_sconv_wgrad_mfma<MT, NT, NW, NGRP><<<grid, 64 * NW, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial);
+}
+
+int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, const int32_t *pg,
+                            const int64_t *k_off, int K, int Cin, int Cout, int n_split, float *partial,
+                            hipStream_t st) {
+    int mt = tile32(Cin), nt = tile32(Cout);
+    dim3 grid((unsigned)(K * n_split), (unsigned)((Cin / (32 * mt)) * (Cout / (32 * nt))));
+#define WG(MT_, NT_, NW_, NG_) launch_wg<MT_, NT_, NW_, NG_>(grid, st, A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial)
+    switch (mt * 10 + nt) {
+        case 11: WG(1, 1, 4, 4); break;
+        case 12: WG(1, 2, 4, 2); break;
+        case 21: WG(2, 1, 4, 2); break;
+        case 13: WG(1, 3, 3, 1); break;
+        case 31: WG(3, 1, 3, 1); break;
+        case 14: WG(1, 4, 4, 1); break;
+        case 41: WG(4, 1, 4, 1); break;
+        case 22: WG(2, 2, 4, 1); break;
+        case 23: WG(2, 3, 3, 1); break;
+        case 32: WG(3, 2, 3, 1); break;
+        case 24: WG(2, 4, 4, 1); break;
+        case 42: WG(4, 2, 4, 1); break;
+        case 33: WG(3, 3, 3, 1); break;
+        case 34: WG(3, 4, 4, 1); break;
+        case 43: WG(4, 3, 4, 1); break;
+        default: WG(4, 4, 4, 1);
+    }
+#undef WG
+    return 0;
+}

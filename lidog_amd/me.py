@@ -273,8 +273,10 @@ def _wgrad_splits(K, Cin, Cout, P):
                 return t
         return c
     tiles = max(1, (Cin // tile(Cin)) * (Cout // tile(Cout)))
-    s = max(1, -(-1024 // (K * tiles)))          # about 4 workgroups per CU
-    s = min(s, 256, max(1, P // (K * 256)))      # but at least 256 pairs per split
+    # The kernel is a latency-bound two-level gather (pair index -> feature row): throughput scales with the
+    # number of resident workgroups, so aim at ~16 per CU; partial slabs cost 4*K*Cin*Cout bytes each.
+    s = max(1, -(-4096 // (K * tiles)))
+    s = min(s, 512, max(1, P // (K * 128)))      # but at least 128 pairs (4 LDS stages) per split
     return s
 
 
@@ -339,7 +341,8 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gW = torch.empty_like(W3)
             ns = _wgrad_splits(K, Cin, Cout, m.P)
-            partial = torch.empty((ns, K, Cin, Cout), dtype=torch.float32, device=x.device) if ns > 1 else None
+            slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, ns)
+            partial = torch.empty((slabs, K, Cin, Cout), dtype=torch.float32, device=x.device) if slabs > 1 else None
             call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(m.k_off), K, Cin, Cout, ns,
                  ptr(partial), ptr(gW))
             gW = gW.view(ctx.w_shape)

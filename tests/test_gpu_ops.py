@@ -92,12 +92,22 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 0], ids=["mfma_f32", "vector_fma"])
+def sparse_core(request):
+    """both arithmetic cores of the sparse GEMMs must give the same (bit-exact) results"""
+    from lidog_amd import _lib
+    L = _lib.load()
+    assert L.lidog_set_sparse_core(request.param) == 0
+    yield request.param
+    L.lidog_set_sparse_core(1)
+
+
 @pytest.mark.parametrize("Cin,Cout,ks,stride,transposed,bias", CONV_CASES)
-def test_sparse_conv_fwd_bwd(Cin, Cout, ks, stride, transposed, bias):
+def test_sparse_conv_fwd_bwd(Cin, Cout, ks, stride, transposed, bias, sparse_core):
     import oracle.me_cpu as OME
     import lidog_amd.me as ME
     OME.set_mode("exact")
-    coords = _rand_coords(7, n=3000, extent=16)
+    coords = _rand_coords(7, n=9000, extent=16)   # ~8.6k voxels: exercises multi-tile and split paths
     so, sg = _maps(coords)
     if transposed:
         so.coordinate_manager.stride(1, 2)
