@@ -93,6 +93,13 @@ int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, cons
 int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
                        float *out, void *stream);
 
+/* lidog_sconv_reduce with the BatchNorm statistics of `out` folded into the same pass: sums[0..C) += sum over
+ * rows of out, sums[C..2C) += sum of squares (fp64, added in a fixed order: bit-reproducible).
+ * partial_ws: lidog_sconv_reduce_stats_ws(n, C) doubles.  C % 4 == 0. */
+int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C);
+int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
+                             float *out, double *sums, double *partial_ws, void *stream);
+
 /* gW[k] = sum over pairs p of segment k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
  * partial: float[n_split * K * Cin * Cout] workspace; the split partials are summed in split order. */
 int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
@@ -117,7 +124,9 @@ int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout,
 
 /* per-channel sums in double: sums[2*C] = (sum x, sum x^2); accumulates into sums (zero it first) */
 int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, void *stream);
-/* mean/invstd from sums and count; updates running stats (momentum, unbiased var) when not NULL */
+/* mean/invstd from sums and count; updates running stats (momentum, unbiased var) when not NULL.
+ * count <= 0: the count is read from sums[2*C] on the device (SyncBatchNorm all-reduces it with the sums);
+ * the same convention holds for lidog_bn_bwd_apply. */
 int lidog_bn_finalize(const double *sums, double count, int32_t C, float eps, float momentum, float *mean,
                       float *invstd, float *running_mean, float *running_var, void *stream);
 /* y = (x - mean) * invstd * w + b (+ residual) (relu).  In-place (y == x) allowed. */

@@ -22,6 +22,8 @@ SIGNATURES = {
     "lidog_kernel_map_pairs": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
     "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_reduce_stats_ws": [_i64, _i32],
+    "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
     "lidog_set_sparse_core": [_i32],
@@ -43,7 +45,7 @@ SIGNATURES = {
     "lidog_conv2d_wgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
     "lidog_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i32, _f, _p],
 }
-_RESTYPES = {"lidog_hash_capacity": _i64}
+_RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64}
 
 _lib = None
 

@@ -187,6 +187,7 @@ __global__ void k_bn_finalize(const double *__restrict__ sums, double count, int
                               float *running_var) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (!(count > 0)) count = sums[2 * C];  // SyncBatchNorm: the all-reduced row count rides behind the sums
     double m = sums[c] / count;
     double var = sums[C + c] / count - m * m;
     if (var < 0) var = 0;
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
         if (ry && !(ry[i] > 0.f)) g = 0.f;
         float is = invstd[c];
         float xh = (x[i] - mean[c]) * is;
-        float m0 = (float)(sums[c] * inv_count), m1 = (float)(sums[C + c] * inv_count);
+        const double ic = (inv_count > 0) ? inv_count : 1.0 / sums[2 * C];
+        float m0 = (float)(sums[c] * ic), m1 = (float)(sums[C + c] * ic);
         dx[i] = (g - m0 - xh * m1) * is * w[c];
         if (dres) dres[i] = g;
     }
@@ -296,7 +298,8 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
     hipStream_t st = (hipStream_t)stream;
     int64_t total = n * C * hw;
     if (total > 0)
-        k_bn_bwd_apply<<<ew_grid(total), 256, 0, st>>>(dy, x, relu_y, total, C, hw, mean, invstd, w, sums, 1.0 / count,
+        k_bn_bwd_apply<<<ew_grid(total), 256, 0, st>>>(dy, x, relu_y, total, C, hw, mean, invstd, w, sums,
+                                                       count > 0 ? 1.0 / count : -1.0,
                                                        dx, dres);
     k_bn_param_grads<<<(C + 127) / 128, 128, 0, st>>>(sums, C, dw, db);
     LIDOG_LAUNCH_CHECK();

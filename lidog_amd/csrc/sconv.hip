@@ -278,6 +278,97 @@ extern "C" int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n,
     return 0;
 }
 
+// Same reduction with the BatchNorm statistics of the result folded in: every workgroup also emits its partial
+// (sum x, sum x^2) per channel in fp64 to partial[block][2C]; k_stats_finish adds the partials in block order
+// (no atomics: the statistics are bit-reproducible) -- saves the separate statistics pass over `out`.
+__global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__restrict__ T,
+                                                             const int32_t *__restrict__ pos, int64_t n, int K, int C4,
+                                                             const float4 *__restrict__ bias, float4 *__restrict__ out,
+                                                             double *__restrict__ partial) {
+    __shared__ double red[256 * 8];
+    const int RB = 256 / C4;
+    const int tid = threadIdx.x;
+    const int r = tid / C4, c4 = tid % C4;
+    const bool active = r < RB;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += (int64_t)gridDim.x * RB) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < K; ++k) {
+                int p = pos[(int64_t)k * n + o];
+                if (p >= 0) {
+                    float4 t = T[(int64_t)p * C4 + c4];
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                }
+            }
+            if (bias) {
+                float4 b = bias[c4];
+                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            }
+            out[o * C4 + c4] = acc;
+            a[0] += acc.x; a[1] += acc.y; a[2] += acc.z; a[3] += acc.w;
+            a[4] += (double)acc.x * acc.x; a[5] += (double)acc.y * acc.y;
+            a[6] += (double)acc.z * acc.z; a[7] += (double)acc.w * acc.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
+    __syncthreads();
+    if (active && r == 0) {
+        const int C = C4 * 4;
+        for (int rr = 1; rr < RB; ++rr)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
+        double *dst = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[c4 * 4 + j] = a[j];
+            dst[C + c4 * 4 + j] = a[4 + j];
+        }
+    }
+}
+
+// one workgroup per 8 channels: 32 lanes stride over the partial blocks, then a fixed-order tree in LDS
+__global__ __launch_bounds__(256) void k_stats_finish(const double *__restrict__ partial, int nb, int C2,
+                                                      double *__restrict__ sums) {
+    __shared__ double red[256];
+    const int cl = threadIdx.x & 7, bl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double s = 0;
+    if (c < C2)
+        for (int b = bl; b < nb; b += 32) s += partial[(size_t)b * C2 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+        if (bl < d) red[threadIdx.x] += red[threadIdx.x + d * 8];
+        __syncthreads();
+    }
+    if (bl == 0 && c < C2) sums[c] += red[cl];
+}
+
+extern "C" int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C) {
+    // doubles of workspace needed by lidog_sconv_reduce_stats
+    (void)n;
+    return (int64_t)2048 * 2 * C;
+}
+
+extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C,
+                                        const float *bias, float *out, double *sums, double *partial_ws,
+                                        void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconv_reduce_stats: C must be a multiple of 4, <= 1024");
+    if (n == 0) return 0;
+    int C4 = C / 4, RB = 256 / C4;
+    int64_t nb = cdiv64(n, (int64_t)RB * 4);
+    if (nb > 2048) nb = 2048;
+    k_sconv_reduce4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, pos, n, K, C4, (const float4 *)bias,
+                                                        (float4 *)out, partial_ws);
+    k_stats_finish<<<(unsigned)cdiv64(2 * C, 8), 256, 0, st>>>(partial_ws, (int)nb, 2 * C, sums);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------ weight gradient
 // gW[k][ci][co] = sum_p A[pa[p]][ci] * G[pg[p]][co] over segment k.  Tile (16*RM) x (16*CN) of one k,
 // pairs processed 32 at a time through LDS (rows stay row-major: no transpose needed for an outer product).

@@ -277,6 +277,7 @@ def _wgrad_splits(K, Cin, Cout, P):
     # number of resident workgroups, so aim at ~16 per CU; partial slabs cost 4*K*Cin*Cout bytes each.
     s = max(1, -(-4096 // (K * tiles)))
     s = min(s, 512, max(1, P // (K * 128)))      # but at least 128 pairs (4 LDS stages) per split
+    s = min(s, max(1, (160 << 20) // (4 * K * Cin * Cout)))  # and at most 160 MB of partial slabs to re-read
     return s
 
 
@@ -286,7 +287,9 @@ class _SparseConvFn(torch.autograd.Function):
     (k2 s2) -> the data gradient scatters straight into `gin`."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, m, swap, single_out, single_in):
+    def forward(ctx, x, W, bias, m, swap, single_out, single_in, stats=None):
+        """`stats`: optional one-element list; when the output goes through the reduction pass, the fp64
+        BatchNorm sums of `out` are produced by that pass and returned in stats[0] (shape [2*Cout+1])."""
         x = x.contiguous()
         W3 = W.contiguous().view(m.K, W.shape[-2], W.shape[-1])
         K, Cin, Cout = W3.shape
@@ -306,7 +309,15 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
             _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
-            call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
+            if stats is not None and Cout % 4 == 0 and Cout <= 1024:
+                sums = torch.zeros(2 * Cout + 1, dtype=torch.float64, device=x.device)
+                ws = torch.empty(_lib.load().lidog_sconv_reduce_stats_ws(n_out, Cout), dtype=torch.float64,
+                                 device=x.device)
+                call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
+                     ptr(ws))
+                stats[0] = sums
+            else:
+                call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
         ctx.save_for_backward(x, W3)
         ctx.m, ctx.swap, ctx.single_in, ctx.has_bias, ctx.w_shape = m, swap, single_in, bias is not None, W.shape
         return out
@@ -348,15 +359,18 @@ class _SparseConvFn(torch.autograd.Function):
             gW = gW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(dim=0, keepdim=True)
-        return gx, gW, gb, None, None, None, None
+        return gx, gW, gb, None, None, None, None, None
 
 
 class _BatchNormFn(torch.autograd.Function):
     """BatchNorm over rows ([n,C], hw=1) or NCHW images (hw=H*W), optional fused residual add and ReLU.
-    `group`: torch.distributed process group for SyncBatchNorm statistics (None = local)."""
+    `group`: torch.distributed process group for SyncBatchNorm statistics (None = local).
+    `sums`: optional fp64 [2C+1] buffer whose first 2C entries already hold (sum x, sum x^2), produced by the
+    epilogue of the convolution that made x (saves one pass over x)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, hw, relu, residual, group):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, hw, relu, residual, group,
+                sums):
         x = x.contiguous()
         if hw == 1:
             n, C = x.shape
@@ -364,14 +378,18 @@ class _BatchNormFn(torch.autograd.Function):
             n, C = x.shape[0], x.shape[1]
         count = float(n * hw)
         dev = x.device
+        count_t = None
         if training:
-            sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-            call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums))
+            if sums is None:
+                sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
+                call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums))
             if group is not None:
+                # (sum x, sum x^2, rows) summed over the ranks in ONE message; the count stays on the device
                 import torch.distributed as dist
-                packed = torch.cat([sums, torch.tensor([count], dtype=torch.float64, device=dev)])
-                dist.all_reduce(packed, group=group)
-                sums, count = packed[:-1].contiguous(), float(packed[-1].item())
+                sums[2 * C] = count
+                dist.all_reduce(sums, group=group)
+                count_t = sums[2 * C:].clone()
+                count = -1.0
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
             call("lidog_bn_finalize", ptr(sums), count, C, float(eps), float(momentum), ptr(mean), ptr(invstd),
@@ -383,48 +401,42 @@ class _BatchNormFn(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         call("lidog_bn_apply", ptr(x), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(res),
              1 if relu else 0, ptr(y))
-        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None, count_t)
         ctx.cfg = (n, C, hw, count, training, residual is not None, group)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, mean, invstd, y = ctx.saved_tensors
+        x, weight, mean, invstd, y, count_t = ctx.saved_tensors
         n, C, hw, count, training, has_res, group = ctx.cfg
         dy = dy.contiguous()
         dev = x.device
-        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
         call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums))
-        dw = torch.empty(C, dtype=torch.float32, device=dev)
-        db = torch.empty(C, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        local = sums
+        # parameter gradients come from the LOCAL sums (DDP averages them afterwards)
+        db = sums[:C].float()
+        dw = sums[C:2 * C].float()
         if not training:
-            # running statistics are constants: dx = dy' * w * invstd
-            red = torch.zeros_like(sums)
+            sums.zero_()  # running statistics are constants: dx = dy' * w * invstd
         elif group is not None:
             import torch.distributed as dist
-            red = sums.clone()
-            dist.all_reduce(red, group=group)
-        else:
-            red = sums
-        call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(red),
+            dist.all_reduce(sums, group=group)
+            sums[2 * C:] = count_t
+        call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(sums),
              count, ptr(dx), ptr(dres), None, None)
-        # parameter gradients come from the LOCAL sums (DDP averages them afterwards)
-        db = local[:C].float()
-        dw = local[C:].float()
-        return dx, dw, db, None, None, None, None, None, None, None, dres, None
+        return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
 
 
-def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None):
-    """functional entry used by the modules below and by lidog_amd.bev_head"""
+def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, sums=None):
+    """functional entry used by the modules below and by lidog_amd.bev"""
     training = bn.training or not bn.track_running_stats
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
-                              hw, relu, residual, group)
+                              hw, relu, residual, group, sums if training else None)
 
 
 # ------------------------------------------------------------------ modules
@@ -454,7 +466,7 @@ class _ConvBase(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
 
-    def forward(self, x):
+    def forward(self, x, stats=None):
         cm, s_in = x.coordinate_manager, x.coordinate_map_key
         if self.kernel_volume == 1 and self.stride == 1:
             m, s_out, swap, single_out, single_in = cm.identity_map(x.F.shape[0]), s_in, False, True, True
@@ -470,7 +482,7 @@ class _ConvBase(nn.Module):
             m = cm.kernel_map(s_out, s_in, self.kernel_size, self.dilation)
             swap, single_in = True, False
             single_out = self.stride == self.kernel_size and self.stride > 1
-        out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in)
+        out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in, stats)
         return SparseTensor(out, coordinate_manager=cm, coordinate_map_key=s_out)
 
 
@@ -490,9 +502,9 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
 
-    def forward(self, x, relu=False, residual=None):
+    def forward(self, x, relu=False, residual=None, sums=None):
         res = residual.F if residual is not None else None
-        return x._like(batch_norm(x.F, self.bn, 1, relu, res, self._sync_group()))
+        return x._like(batch_norm(x.F, self.bn, 1, relu, res, self._sync_group(), sums))
 
     def _sync_group(self):
         return None
@@ -536,6 +548,14 @@ class MinkowskiReLU(nn.Module):
         f = x.F
         inplace = self.inplace and not (f.requires_grad and f.is_leaf)
         return x._like(_ReLUFn.apply(f, inplace))
+
+
+def conv_bn(conv, bn_module, x, relu=False, residual=None):
+    """convolution + BatchNorm (+ residual add + ReLU): the BN statistics come out of the convolution's
+    reduction pass, the affine/add/ReLU is one fused elementwise pass"""
+    holder = [None] if (bn_module.bn.training or not bn_module.bn.track_running_stats) else None
+    y = conv(x, stats=holder)
+    return bn_module(y, relu=relu, residual=residual, sums=holder[0] if holder is not None else None)
 
 
 def bn_relu(bn_module, x):
@@ -610,9 +630,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.norm1(self.conv1(x), relu=True)
+        out = conv_bn(self.conv1, self.norm1, x, relu=True)
         residual = x if self.downsample is None else self.downsample(x)
-        return self.norm2(self.conv2(out), relu=True, residual=residual)
+        return conv_bn(self.conv2, self.norm2, out, relu=True, residual=residual)
 
 
 class Bottleneck(nn.Module):

@@ -30,6 +30,7 @@ BEV_LEVEL_CHANNELS = {"block8": 96, "block7": 96, "block6": 128, "bottle": 256}
 def make_models(ME, Encoder2D=None, sparse2super=None):
     BasicBlock = ME.modules.resnet_block.BasicBlock
     _fused = getattr(ME, "bn_relu", None)  # optional backend fast path: BN + ReLU in one kernel
+    _conv_bn = getattr(ME, "conv_bn", None)
 
     class _Trunk(nn.Module):
         BLOCK = BasicBlock
@@ -83,21 +84,24 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
         def _bn_relu(self, bn, x):
             return _fused(bn, x) if _fused is not None else self.relu(bn(x))
 
+        def _conv_bn_relu(self, conv, bn, x):
+            if _conv_bn is not None:  # backend fast path: BN statistics from the convolution's own epilogue
+                return _conv_bn(conv, bn, x, relu=True)
+            return self._bn_relu(bn, conv(x))
+
         def _trunk_forward(self, x):
             """returns (out_block8, out_bottle, {level: tensor})"""
-            out = self._bn_relu(self.bn0, self.conv0p1s1(x))
+            out = self._conv_bn_relu(self.conv0p1s1, self.bn0, x)
             skips = [out]
             for i, s in _ENC:
-                out = getattr(self, f"conv{i}p{s}s2")(out)
-                out = self._bn_relu(getattr(self, f"bn{i}"), out)
+                out = self._conv_bn_relu(getattr(self, f"conv{i}p{s}s2"), getattr(self, f"bn{i}"), out)
                 out = getattr(self, f"block{i}")(out)
                 skips.append(out)
             bottle = skips.pop()
             levels = {}
             names = ["bottle", "block6", "block7", "block8"]
             for (j, s), name in zip(_DEC, names):
-                out = getattr(self, f"convtr{j}p{s}s2")(out)
-                out = self._bn_relu(getattr(self, f"bntr{j}"), out)
+                out = self._conv_bn_relu(getattr(self, f"convtr{j}p{s}s2"), getattr(self, f"bntr{j}"), out)
                 out = ME.cat(out, skips.pop())
                 out = getattr(self, f"block{j + 1}")(out)
                 levels[name] = out
