@@ -225,6 +225,38 @@ extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const flo
 }
 
 // ------------------------------------------------------------------ per-row reduction over kernel offsets
+// out row = sum over k ascending of T[pos[k][o]] (missing neighbours add an exact 0).  Loads are issued in
+// independent batches of 9 / 4 (position first, then product rows, unconditionally -- a missing neighbour
+// reads row 0, which stays in L1): a branch per offset would expose one full memory round trip per offset.
+template <int G>
+__device__ __forceinline__ void reduce_group(const float4 *__restrict__ T, const int32_t *__restrict__ pos, int64_t n,
+                                             int C4, int64_t o, int c4, int k, float4 &acc) {
+    int p[G];
+    float4 t[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) p[j] = pos[(int64_t)(k + j) * n + o];
+#pragma unroll
+    for (int j = 0; j < G; ++j) t[j] = T[(int64_t)(p[j] < 0 ? 0 : p[j]) * C4 + c4];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        bool ok = p[j] >= 0;
+        acc.x += ok ? t[j].x : 0.f;
+        acc.y += ok ? t[j].y : 0.f;
+        acc.z += ok ? t[j].z : 0.f;
+        acc.w += ok ? t[j].w : 0.f;
+    }
+}
+
+__device__ __forceinline__ float4 reduce_row(const float4 *__restrict__ T, const int32_t *__restrict__ pos, int64_t n,
+                                             int K, int C4, int64_t o, int c4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 9 <= K; k += 9) reduce_group<9>(T, pos, n, C4, o, c4, k, acc);
+    for (; k + 4 <= K; k += 4) reduce_group<4>(T, pos, n, C4, o, c4, k, acc);
+    for (; k < K; ++k) reduce_group<1>(T, pos, n, C4, o, c4, k, acc);
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_sconv_reduce4(const float4 *__restrict__ T, const int32_t *__restrict__ pos,
                                                        int64_t n, int K, int C4, const float4 *__restrict__ bias,
                                                        float4 *__restrict__ out) {
@@ -232,14 +264,7 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4(const float4 *__restrict_
     if (idx >= n * C4) return;
     int64_t o = idx / C4;
     int c4 = (int)(idx % C4);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < K; ++k) {
-        int p = pos[(int64_t)k * n + o];
-        if (p >= 0) {
-            float4 t = T[(int64_t)p * C4 + c4];
-            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-        }
-    }
+    float4 acc = reduce_row(T, pos, n, K, C4, o, c4);
     if (bias) {
         float4 b = bias[c4];
         acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
@@ -293,14 +318,7 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__res
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += (int64_t)gridDim.x * RB) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < K; ++k) {
-                int p = pos[(int64_t)k * n + o];
-                if (p >= 0) {
-                    float4 t = T[(int64_t)p * C4 + c4];
-                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-                }
-            }
+            float4 acc = reduce_row(T, pos, n, K, C4, o, c4);
             if (bias) {
                 float4 b = bias[c4];
                 acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;

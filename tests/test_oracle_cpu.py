@@ -212,7 +212,8 @@ def test_tile_descriptors_and_offsets():
     from lidog_amd.me import _tiles, kernel_offsets
     desc, n = _tiles([0, 5, 5, 300, 428], "cpu")
     assert n == 5
-    assert desc.tolist() == [[0, 2, 2, 2, 3], [0, 5, 133, 261, 300], [5, 128, 128, 39, 128]]
+    # 128-row tiles that never straddle an offset, launched in order of relative position inside their segment
+    assert desc.tolist() == [[2, 0, 2, 3, 2], [5, 0, 133, 300, 261], [128, 5, 128, 128, 39]]
     o3 = kernel_offsets(3, 2)
     assert o3.shape == (27, 3) and o3[0].tolist() == [-2, -2, -2] and o3[1].tolist() == [0, -2, -2]
     assert o3[13].tolist() == [0, 0, 0]
