@@ -228,6 +228,153 @@ __global__ __launch_bounds__(256) void k_igemm(IgParams p) {
     }
 }
 
+// ------------------------------------------------------------------ FWD / DGRAD, second generation
+// Same tiling as k_igemm, but 32-deep stages and all reduction-index arithmetic on the scalar unit: the
+// reduction row kk of a staged B element is wave-uniform (kw + 2r), so (ci,ky,kx) / (co,tap) and the address
+// offset they imply are SGPR values; per lane only a validity bit (precomputed 3-bit row/column masks), one
+// add and two selects remain.  Invalid taps load a known-good address and are zeroed by select (no branch
+// around a load).
+#define C2_KB 32
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
+    __shared__ float As[C2_KB * IG_LD];
+    __shared__ float Bs[C2_KB * IG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * IG_T, j0 = blockIdx.x * IG_T;
+    const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+    const int kw = __builtin_amdgcn_readfirstlane(tid >> 7);
+
+    // ---- the pixel of this lane (fixed for the whole kernel)
+    const int j = j0 + (tid & 127);
+    const bool jvalid = j < p.Nj;
+    const int jj = jvalid ? j : 0;
+    size_t base, safe;
+    unsigned ymask = 0, xmask = 0;
+    if (MODE == IG_FWD) {
+        int pb = jj / HoWo, r = jj - pb * HoWo;
+        int yo = r / p.Wo, xo = r - yo * p.Wo;
+        base = (size_t)pb * p.Cin * HW + (size_t)(2 * yo) * p.W + 2 * xo;  // centre tap, always inside the image
+        safe = base;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int y = 2 * yo - 1 + t, x = 2 * xo - 1 + t;
+            ymask |= (unsigned)(y >= 0 && y < p.H) << t;
+            xmask |= (unsigned)(x >= 0 && x < p.W) << t;
+        }
+    } else {
+        int hw = p.Hc * p.Wc;
+        int pb = jj / hw, r = jj - pb * hw;
+        int pyy = (r / p.Wc) * 2 + p.py, pxx = (r % p.Wc) * 2 + p.px;
+        int y0 = (pyy + 1 - p.ky0) >> 1, x0 = (pxx + 1 - p.kx0) >> 1;  // output pixel of the class's first tap
+        safe = (size_t)pb * p.Cout * HoWo;
+        base = safe + (size_t)y0 * p.Wo + x0;   // y0 - t / x0 - t for the later taps
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ymask |= (unsigned)(y0 - t >= 0 && y0 - t < p.Ho) << t;
+            xmask |= (unsigned)(x0 - t >= 0 && x0 - t < p.Wo) << t;
+        }
+    }
+    if (!jvalid) ymask = 0;
+    const int nt = p.nky * p.nkx;
+
+    float ra[16], rb[16];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int f = tid + 256 * v;
+            int i = i0 + (f >> 3), q = f & 7;
+            bool iok = i < p.Mi;
+            float4 t = *reinterpret_cast<const float4 *>(p.A + (size_t)(iok ? i : p.Mi - 1) * p.Kd + k0 + q * 4);
+            ra[4 * v] = iok ? t.x : 0.f; ra[4 * v + 1] = iok ? t.y : 0.f;
+            ra[4 * v + 2] = iok ? t.z : 0.f; ra[4 * v + 3] = iok ? t.w : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + kw + 2 * r;  // wave-uniform
+            int koff, ty, tx;
+            if (MODE == IG_FWD) {
+                int ci = kk / 9, t = kk - ci * 9;
+                ty = t / 3; tx = t - ty * 3;
+                koff = ci * HW + (ty - 1) * p.W + (tx - 1);
+            } else {
+                int co = kk / nt, tap = kk - co * nt;
+                ty = tap / p.nkx; tx = tap - ty * p.nkx;
+                koff = co * HoWo - ty * p.Wo - tx;
+            }
+            bool ok = ((ymask >> ty) & (xmask >> tx) & 1u) != 0;
+            size_t addr = ok ? (size_t)((long long)base + koff) : safe;
+            float v = p.Bm[addr];
+            rb[r] = ok ? v : 0.f;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int f = tid + 256 * v;
+            int il = f >> 3, q = f & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(q * 4 + e) * IG_LD + il] = ra[4 * v + e];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Bs[(kw + 2 * r) * IG_LD + (tid & 127)] = rb[r];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+    const int li = lane & 31, kh = lane >> 5;
+
+    load_stage(0);
+    for (int k0 = 0; k0 < p.Kd; k0 += C2_KB) {
+        __syncthreads();
+        store_stage();
+        __syncthreads();
+        load_stage(k0 + C2_KB < p.Kd ? k0 + C2_KB : k0);  // unconditional prefetch (last stage re-reads itself)
+#pragma unroll
+        for (int k2 = 0; k2 < C2_KB / 2; ++k2) {
+            float a0 = As[(2 * k2 + kh) * IG_LD + wi + li];
+            float a1 = As[(2 * k2 + kh) * IG_LD + wi + 32 + li];
+            float b0 = Bs[(2 * k2 + kh) * IG_LD + wj + li];
+            float b1 = Bs[(2 * k2 + kh) * IG_LD + wj + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        int jo = j0 + wj + 32 * tj + li;
+        if (jo >= p.Nj) continue;
+        size_t col_off, i_stride;
+        if (MODE == IG_FWD) {
+            int b = jo / HoWo;
+            col_off = (size_t)b * p.Cout * HoWo + (jo - b * HoWo);
+            i_stride = HoWo;
+        } else {
+            int hw = p.Hc * p.Wc;
+            int b = jo / hw, r = jo - b * hw;
+            int y = (r / p.Wc) * 2 + p.py, x = (r % p.Wc) * 2 + p.px;
+            col_off = (size_t)b * p.Cin * HW + (size_t)y * p.W + x;
+            i_stride = HW;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int i = i0 + wi + 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (i < p.Mi) p.D[col_off + (size_t)i * i_stride] = acc[ti][tj][e];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ weight repack for DGRAD
 // Wd[ci][co*nt + tap] = W[co][ci][ky(tap)][kx(tap)] for one parity class
 __global__ __launch_bounds__(256) void k_repack_dgrad(const float *__restrict__ W, int Cin, int Cout, int nky,
@@ -346,7 +493,7 @@ extern "C" int lidog_conv2d_fwd(const float *x, const float *w, const float *bia
     }
     LIDOG_REQUIRE(ksize == 3 && stride == 2 && pad == 1 && bias == nullptr,
                   "conv2d_fwd: MFMA path implements k3 s2 p1 without bias (Encoder2D)");
-    LIDOG_REQUIRE((Cin * 9) % IG_KB == 0, "conv2d_fwd: Cin*9 must be a multiple of 16");
+    LIDOG_REQUIRE((Cin * 9) % C2_KB == 0, "conv2d_fwd: Cin*9 must be a multiple of 32");
     IgParams p = {};
     p.A = w; p.Bm = x; p.D = y;
     p.Bn = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
@@ -354,7 +501,7 @@ extern "C" int lidog_conv2d_fwd(const float *x, const float *w, const float *bia
     p.Mi = Cout; p.Nj = B * p.Ho * p.Wo; p.Kd = Cin * 9;
     if (p.Nj == 0) return 0;
     dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
-    k_igemm<IG_FWD><<<grid, 256, 0, st>>>(p);
+    k_conv_s2<IG_FWD><<<grid, 256, 0, st>>>(p);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -372,7 +519,7 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
     }
     LIDOG_REQUIRE(ksize == 3 && stride == 2 && pad == 1, "conv2d_dgrad: MFMA path implements k3 s2 p1");
     LIDOG_REQUIRE(ws != nullptr, "conv2d_dgrad: needs a 9*Cin*Cout float workspace for the repacked weights");
-    LIDOG_REQUIRE(Cout % IG_KB == 0, "conv2d_dgrad: Cout must be a multiple of 16");
+    LIDOG_REQUIRE(Cout % C2_KB == 0, "conv2d_dgrad: Cout must be a multiple of 32");
     int Ho = out_dim(H, 3, 2, 1), Wo = out_dim(W, 3, 2, 1);
     float *slab = ws;
     for (int py = 0; py < 2; ++py) {
@@ -394,7 +541,7 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
             slab += total;
             if (p.Nj > 0) {
                 dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
-                k_igemm<IG_DGRAD><<<grid, 256, 0, st>>>(p);
+                k_conv_s2<IG_DGRAD><<<grid, 256, 0, st>>>(p);
             }
         }
     }
