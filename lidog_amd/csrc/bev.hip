@@ -55,13 +55,17 @@ __global__ __launch_bounds__(256) void k_bev_pool_fwd(const float *__restrict__ 
     for (int dy = 0; dy < pk; ++dy) {
         int yy = yo * ps - pp + dy;
         if (yy < 0 || yy >= H) continue;
-        for (int dx = 0; dx < pk; ++dx) {
-            int xx = xo * ps - pp + dx;
-            if (xx < 0 || xx >= W) continue;
-            int64_t f = (int64_t)cp * HW + (int64_t)yy * W + xx;
-            int64_t pix = f / C;
-            int ch = (int)(f - pix * C);
-            int row = win[pix];
+        // the window's cells of one view row are consecutive flat indices: they fall on one pixel (or two at a
+        // multiple of C), so the pixel's winner is looked up once per row, not once per cell
+        int x_lo = xo * ps - pp, x_hi = x_lo + pk;
+        if (x_lo < 0) x_lo = 0;
+        if (x_hi > W) x_hi = W;
+        // 32-bit index math (the launcher checks C*H*W < 2^31): a 64-bit division costs ~100 instructions
+        unsigned f = (unsigned)cp * (unsigned)HW + (unsigned)yy * (unsigned)W + (unsigned)x_lo;
+        unsigned pix = f / (unsigned)C;
+        int ch = (int)(f - pix * (unsigned)C);
+        int row = win[pix];
+        for (int xx = x_lo; xx < x_hi; ++xx) {
             float v = 0.f;
             int32_t s = -1;
             if (row >= 0) {
@@ -71,6 +75,11 @@ __global__ __launch_bounds__(256) void k_bev_pool_fwd(const float *__restrict__ 
             if (v > best) {
                 best = v;
                 src = s;
+            }
+            if (++ch == C) {
+                ch = 0;
+                ++pix;
+                if (xx + 1 < x_hi) row = win[pix];
             }
         }
     }
@@ -83,7 +92,7 @@ extern "C" int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *
                                   int32_t *argsrc, void *stream) {
     int64_t total = (int64_t)B * C * Ho * Wo;
     if (total == 0) return 0;
-    LIDOG_REQUIRE(((int64_t)H * W) % 1 == 0 && (int64_t)H * W * C < ((int64_t)1 << 40), "bev_pool_fwd: image too large");
+    LIDOG_REQUIRE((int64_t)H * W * C < ((int64_t)1 << 31), "bev_pool_fwd: C*H*W must stay below 2^31");
     k_bev_pool_fwd<<<(unsigned)cdiv64(total, 256), 256, 0, (hipStream_t)stream>>>(feats, C, winner, H, W, pk, ps, pp, Ho,
                                                                                 Wo, total, out, argsrc);
     LIDOG_LAUNCH_CHECK();
