@@ -169,6 +169,24 @@ int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, int32_t Cin, 
                        int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *gw, float *gbias,
                        float *ws, int64_t ws_floats, void *stream);
 
+/* ------------------------------------------------------------------ data path next to the hot path
+ * ME.utils.sparse_quantize (utils/datasets/semantickitti_bev.py:232-238) = lidog_voxel_floor +
+ * lidog_coords_insert + lidog_coords_compact + lidog_label_vote; PC2ImgConverter.getBEVImageNew
+ * (utils/datasets/semantickitti_bev.py:433-464) = lidog_bev_label_raster. */
+/* rows[i] = (batch, floor(x/qx), floor(y/qy), floor(z/qz)) in float32 arithmetic; points [n,3] */
+int lidog_voxel_floor(const float *points, int64_t n, float qx, float qy, float qz, int32_t batch, int32_t *rows,
+                      void *stream);
+/* voxel_labels[j] = label of the voxel's first point, or ignore_label when its points disagree */
+int lidog_label_vote(const int32_t *labels, const int32_t *unique_rows, const int32_t *inverse, int64_t n, int64_t m,
+                     int32_t ignore_label, int32_t *voxel_labels, void *stream);
+/* point_idx [B,S,S] (pre-filled with -1) = index inside its scan of the last labelled in-bounds voxel per pixel,
+ * img_labels [B,S,S] int64 = its label or -1.  lut_x/lut_y: pixel per integer coordinate or -1, lut_z: 1 inside
+ * the z range.  batch_start [B+1]: first row of every scan. */
+int lidog_bev_label_raster(const int32_t *coords, const int32_t *labels, int64_t n, const int32_t *lut_x,
+                           const int32_t *lut_y, const int32_t *lut_z, int32_t lut_lo, int32_t lut_n, int32_t B,
+                           int32_t S, const int64_t *batch_start, int32_t *point_idx, int64_t *img_labels,
+                           void *stream);
+
 /* ------------------------------------------------------------------ optimiser
  * Replaces torch.optim.Adam(lr, weight_decay) of trainer_lighting_2d.py:356-358 on a flat buffer. */
 int lidog_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,

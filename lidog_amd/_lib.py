@@ -43,6 +43,9 @@ SIGNATURES = {
     "lidog_conv2d_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_conv2d_dgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_conv2d_wgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
+    "lidog_voxel_floor": [_p, _i64, _f, _f, _f, _i32, _p, _p],
+    "lidog_label_vote": [_p, _p, _p, _i64, _i64, _i32, _p, _p],
+    "lidog_bev_label_raster": [_p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
     "lidog_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i32, _f, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64}

@@ -13,6 +13,7 @@ What executes reference code here:
                                MinkowskiEngine 0.5.4 is not installable here ("parity unpinned"
                                at that boundary, see oracle/me_oracle.c)
   G6  MinkUNet34            <- utils/models/minkunet.py class, same arrangement
+  G7  BEV label images      <- PC2ImgConverter.getBEVImageNew (utils/datasets/semantickitti_bev.py:433-464)
 """
 import hashlib
 import os
@@ -236,8 +237,46 @@ def g6_unet():
     print("G6", N, float(loss))
 
 
+def g7_bev_labels():
+    """PC2ImgConverter.getBEVImageNew (reference code) on voxel coordinates: the BEV label rasteriser (N2).
+    torchvision is not installed and the file uses np.int (removed from numpy): both are patched for the import
+    only; the method itself is pure numpy."""
+    import types
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvt.Compose = object
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    sys.modules.setdefault("tqdm", types.ModuleType("tqdm"))
+    if not hasattr(np, "int"):
+        np.int = int
+    from utils.datasets.semantickitti_bev import PC2ImgConverter
+    rng = np.random.default_rng(41)
+    out = {}
+    for bound, size in ((50.0, 167), (30.0, 100)):
+        n = 12000
+        vox = np.stack([rng.integers(-1250, 1250, n), rng.integers(-1250, 1250, n), rng.integers(-220, 180, n)], axis=1)
+        # include the coordinates that sit on the float32 bound and many collisions per pixel
+        vox[:40, 0] = np.array([int(bound / 0.05) - 1, -int(bound / 0.05) + 1] * 20)
+        vox = np.unique(vox, axis=0)
+        vox = vox[rng.permutation(vox.shape[0])].astype(np.int32)
+        labels = rng.integers(-1, 7, vox.shape[0])
+        grid = (bound - (-bound)) / size
+        conv = PC2ImgConverter(imgChannel=1, xRange=[-bound, bound], yRange=[-bound, bound], zRange=[-10, 8],
+                               xGridSize=grid, yGridSize=grid, zGridSize=0.3)
+        pts = (vox * 0.05).astype(np.float32)
+        img, idx = conv.getBEVImageNew(pts, labels)
+        tag = str(int(bound))
+        out.update({f"vox_{tag}": vox, f"labels_{tag}": labels, f"img_{tag}": img.astype(np.int32),
+                    f"idx_{tag}": idx.astype(np.int32)})
+        print("G7", bound, img.shape, int((img >= 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "g7_bev_labels.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
-    fns = dict(g1=g1_luts, g2=g2_sparse2super, g3=g3_encoder2d, g4=g4_losses, g5=g5_full_model, g6=g6_unet)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    fns = dict(g1=g1_luts, g2=g2_sparse2super, g3=g3_encoder2d, g4=g4_losses, g5=g5_full_model, g6=g6_unet,
+               g7=g7_bev_labels)
     for w in which:
         fns[w]()

@@ -280,3 +280,25 @@ def test_reference_model_file_builds_on_product_api():
     out = subprocess.run([sys.executable, "-B", "-c", code], capture_output=True, text=True,
                          env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_bev_label_luts_reproduce_reference_golden():
+    """host arithmetic of lidog_amd.data.label_luts against images made by the reference's getBEVImageNew"""
+    from lidog_amd.data import label_luts
+    g7 = np.load(f"{GOLDEN}/g7_bev_labels.npz")
+    for bound, size in ((50.0, 167), (30.0, 100)):
+        tag = str(int(bound))
+        vox, lab = g7[f"vox_{tag}"], g7[f"labels_{tag}"]
+        lx, ly, lz, lo, S = label_luts(bound, size, 0.05)
+        assert S == size
+        j = vox - lo
+        ok = (lab != -1) & (j >= 0).all(1) & (j < lx.shape[0]).all(1)
+        jj = np.clip(j, 0, lx.shape[0] - 1)
+        px, py, pz = lx[jj[:, 0]], ly[jj[:, 1]], lz[jj[:, 2]]
+        ok &= (px >= 0) & (py >= 0) & (pz == 1)
+        img = -np.ones((S, S), np.int32)
+        idx = -np.ones((S, S), np.int32)
+        rows = np.nonzero(ok)[0]
+        img[py[rows], px[rows]] = lab[rows]   # numpy assignment order: the last row wins, as in the reference
+        idx[py[rows], px[rows]] = rows
+        assert np.array_equal(img, g7[f"img_{tag}"]) and np.array_equal(idx, g7[f"idx_{tag}"])
