@@ -1,0 +1,58 @@
+"""Evaluation path: forward-only inference and the reference's mIoU definition.
+
+  test_step      utils/pipelines/trainer_lighting_bev.py:265-323  -- per-scan per-class Jaccard over ALL points
+                 (sklearn.metrics.jaccard_score with labels 0..C-1, so points labelled -1 still enlarge the union
+                 of the class they are predicted as), -1 for classes absent from the scan's labels
+  test_epoch_end utils/pipelines/trainer_lighting_bev.py:325-383  -- -1 -> NaN, nan-mean over scans per class,
+                 x100, nan-mean over classes
+Everything stays on the device (the reference moves predictions to the CPU for sklearn)."""
+import torch
+
+from . import me as ME
+
+
+def per_class_iou(preds, labels, num_classes=7, ignore_label=-1):
+    """[C] IoU per class, -1 where the class does not occur in `labels`."""
+    preds, labels = preds.long().view(-1), labels.long().view(-1)
+    iou = torch.empty(num_classes, dtype=torch.float64, device=preds.device)
+    cls = torch.arange(num_classes, device=preds.device).view(-1, 1)
+    p, l = preds.view(1, -1) == cls, labels.view(1, -1) == cls
+    inter = (p & l).sum(dim=1).double()
+    union = (p | l).sum(dim=1).double()
+    iou = torch.where(union > 0, inter / union.clamp(min=1), torch.zeros_like(inter))   # zero_division=0
+    present = l.any(dim=1)
+    return torch.where(present, iou, -torch.ones_like(iou))
+
+
+def mean_iou(per_scan_iou):
+    """[n_scans, C] with -1 for absent classes -> (per-class IoU in percent, mean IoU), NaN-aware"""
+    x = per_scan_iou.clone().double()
+    x[x == -1] = float("nan")
+    per_class = torch.nanmean(x, dim=0) * 100
+    return per_class, torch.nanmean(per_class)
+
+
+@torch.no_grad()
+def predict(model, coords, feats):
+    """validation / test forward: is_train=False (no BEV head, running BN statistics), arg-max class per voxel"""
+    was_training = model.training
+    model.eval()
+    out = model(ME.SparseTensor(coordinates=coords, features=feats))
+    logits = (out[0] if isinstance(out, tuple) else out).F
+    model.train(was_training)
+    return logits.max(dim=1)[1], logits
+
+
+@torch.no_grad()
+def evaluate(model, batches, num_classes=7, ignore_label=-1):
+    """batches: iterable of dicts with coords_int [N,4], source_features0, source_sem_labels0 (one IoU row per
+    scan, as test_step is called with batch size 1 in eval_target.py)"""
+    rows = []
+    for b in batches:
+        coords = b["coords_int"]
+        preds, _ = predict(model, coords, b["source_features0"])
+        labels = b["source_sem_labels0"]
+        for s in range(int(coords[:, 0].max().item()) + 1):
+            sel = coords[:, 0] == s
+            rows.append(per_class_iou(preds[sel], labels[sel], num_classes, ignore_label))
+    return mean_iou(torch.stack(rows))

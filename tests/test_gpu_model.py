@@ -36,6 +36,14 @@ def test_minkunet34bev_matches_reference_golden():
     assert none0 is None
     d0 = (sem0.F.cpu() - torch.from_numpy(g5["eval_logits_initial"])).abs().max().item()
     assert d0 <= 1e-4, f"eval-mode logits differ by {d0}"
+    # mIoU parity (the paper's quality metric, trainer_lighting_bev.py:265-383) on the synthetic labels
+    from lidog_amd.evaluate import per_class_iou, predict
+    preds, _ = predict(model, C, feats)
+    ref_preds = torch.from_numpy(g5["eval_logits_initial"]).max(dim=1)[1]
+    assert (preds.cpu() != ref_preds).float().mean().item() <= 1e-3   # only exact near-ties may flip
+    iou_g = per_class_iou(preds, labels, 7, -1).cpu()
+    iou_r = per_class_iou(ref_preds, labels.cpu(), 7, -1)
+    assert (iou_g - iou_r).abs().max().item() <= 1e-3
     model.train()
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-4)
     sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)

@@ -302,3 +302,28 @@ def test_bev_label_luts_reproduce_reference_golden():
         img[py[rows], px[rows]] = lab[rows]   # numpy assignment order: the last row wins, as in the reference
         idx[py[rows], px[rows]] = rows
         assert np.array_equal(img, g7[f"img_{tag}"]) and np.array_equal(idx, g7[f"idx_{tag}"])
+
+
+def test_iou_definition_matches_sklearn_as_the_reference_calls_it():
+    """trainer_lighting_bev.py:282-293: jaccard_score(preds, labels, average=None, labels=arange(C), zero_division=0)
+    with absent classes set to -1, then nan-mean aggregation (:356-370)"""
+    from sklearn.metrics import jaccard_score
+    from lidog_amd.evaluate import per_class_iou, mean_iou
+    g = torch.Generator().manual_seed(3)
+    rows, ref_rows = [], []
+    for n in (500, 37, 1200):
+        preds = torch.randint(0, 7, (n,), generator=g)
+        labels = torch.randint(-1, 5 if n == 37 else 7, (n,), generator=g)   # one scan without classes 5, 6
+        ref = jaccard_score(preds.numpy(), labels.numpy(), average=None, labels=np.arange(7), zero_division=0.)
+        present = np.unique(labels.numpy())
+        present = present[present != -1]
+        r = -np.ones(7)
+        r[present] = ref[present]
+        got = per_class_iou(preds, labels, 7, -1)
+        assert np.allclose(got.numpy(), r, atol=1e-12)
+        rows.append(got)
+        ref_rows.append(r)
+    per_class, mean = mean_iou(torch.stack(rows))
+    m = np.stack(ref_rows)
+    m[m == -1] = np.nan
+    assert np.allclose(per_class.numpy(), np.nanmean(m, axis=0) * 100) and abs(float(mean) - np.nanmean(np.nanmean(m, axis=0) * 100)) < 1e-9
