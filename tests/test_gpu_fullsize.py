@@ -1,0 +1,137 @@
+"""Full-size checks on the GPU (BASELINE.json configs, where the CPU oracle would take minutes): size-independent
+properties of the coordinate maps and of the convolution, run-to-run bit reproducibility, and the training
+steps of configs 1, 2, 4 and the forward of config 5 (461 k-voxel stress case)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tensor(config, seeds, mix3d=False):
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    b = synth.make_batch(seeds, config, "cuda", mix3d=mix3d)
+    return ME.SparseTensor(coordinates=b["coords_int"], features=b["source_features0"]), b
+
+
+def test_maps_at_120k_points():
+    st, _ = _tensor("kitti120k", [0, 1])
+    cm = st.coordinate_manager
+    prev, n_prev = 1, cm.maps[1].n
+    for s in (2, 4, 8, 16):
+        m = cm.stride(prev, s)
+        c = m.coords
+        assert m.n < n_prev and torch.all(c[:, 1:] % s == 0)                      # on the coarser lattice
+        assert torch.unique(c, dim=0).shape[0] == m.n                              # no duplicates
+        # every parent floors onto a row of the child map, and first-occurrence order is monotone
+        par = cm.maps[prev].coords.clone()
+        par[:, 1:] = torch.div(par[:, 1:], s, rounding_mode="floor") * s
+        km = cm.kernel_map(prev, s, 2)                                             # k2 s2: exactly one pair per parent
+        assert km.P == n_prev and torch.equal(torch.sort(km.pair_in)[0].long(), torch.arange(n_prev, device="cuda"))
+        assert torch.equal(c[km.pair_out.long()][:, 0], par[km.pair_in.long()][:, 0])
+        prev, n_prev = s, m.n
+    # 3^3 map: symmetric under (k, in, out) <-> (26 - k, out, in); the centre offset is the identity
+    km = cm.kernel_map(1, 1, 3)
+    K = km.K
+    off = torch.tensor(km.k_off_host, device="cuda")
+    ks = torch.repeat_interleave(torch.arange(K, device="cuda"), off[1:] - off[:-1])
+    n = cm.maps[1].n
+    key = (ks * n + km.pair_in.long()) * n + km.pair_out.long()
+    mirrored = ((K - 1 - ks) * n + km.pair_out.long()) * n + km.pair_in.long()
+    assert torch.equal(torch.sort(key)[0], torch.sort(mirrored)[0])
+    a, b = km.k_off_host[13], km.k_off_host[14]
+    assert b - a == n and torch.equal(km.pair_in[a:b], km.pair_out[a:b])
+
+
+def test_conv_linearity_adjointness_and_reproducibility_at_120k_points():
+    import lidog_amd.me as ME
+    st, _ = _tensor("kitti120k", [2])
+    cm, n = st.coordinate_manager, st.F.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    conv = ME.MinkowskiConvolution(96, 96, kernel_size=3, dimension=3).cuda()
+    x = torch.randn(n, 96, device="cuda", generator=g, requires_grad=True)
+    y = torch.randn(n, 96, device="cuda", generator=g)
+    gy = torch.randn(n, 96, device="cuda", generator=g)
+    f = lambda t: conv(ME.SparseTensor(t, coordinate_manager=cm, coordinate_map_key=1)).F
+    out = f(x)
+    lin = f(2.0 * x.detach() - 0.5 * y)
+    ref = 2.0 * out.detach() - 0.5 * f(y)
+    assert (lin - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    out.backward(gy)
+    # <conv(x), g> == <x, conv^T(g)>  (the data gradient is the adjoint)   and   == <W, dW>
+    lhs = (out.detach().double() * gy.double()).sum()
+    assert abs(float(lhs - (x.detach().double() * x.grad.double()).sum())) <= 1e-5 * abs(float(lhs))
+    assert abs(float(lhs - (conv.kernel.detach().double() * conv.kernel.grad.double()).sum())) <= 1e-4 * abs(float(lhs))
+    # no atomics in the convolution: forward, data gradient and weight gradient are bit-reproducible
+    gx1, gw1 = x.grad.clone(), conv.kernel.grad.clone()
+    x.grad, conv.kernel.grad = None, None
+    out2 = f(x)
+    out2.backward(gy)
+    assert torch.equal(out2, out) and torch.equal(x.grad, gx1) and torch.equal(conv.kernel.grad, gw1)
+
+
+def test_bev_projection_properties_at_full_image():
+    """B = 50 m (2000 x 2000 px): gradient mass is conserved through pool + scatter for non-colliding voxels"""
+    import lidog_amd.me as ME
+    from lidog_amd.bev import sparse2super
+    st, _ = _tensor("kitti120k", [3, 4])
+    n = st.F.shape[0]
+    feats = torch.rand(n, 96, device="cuda").requires_grad_(True)
+    x = ME.SparseTensor(feats, coordinate_manager=st.coordinate_manager, coordinate_map_key=1)
+    out = sparse2super(x, bound=50.0)
+    assert tuple(out.shape) == (2, 96, 666, 666) and float(out.min()) >= 0.0
+    assert float(out.max()) == float(feats.max())            # max-pool of scattered values: the global max survives
+    gout = torch.rand_like(out)
+    out.backward(gout)
+    assert torch.isfinite(feats.grad).all() and float(feats.grad.sum()) > 0
+    out2 = sparse2super(x, bound=50.0)
+    assert torch.equal(out, out2)                             # atomicMax winner map: deterministic
+
+
+@pytest.mark.parametrize("name", ["c1_source8k", "c4_mix3d"])
+def test_source_training_configs_learn(name):
+    """configs[0] (train_source MinkUNet34, 8k points, 0.1 m voxels, bs 4) and configs[3] (Mix3D union of two
+    nuScenes-like scans): a few Adam steps on a fixed batch must reduce the SoftDICE loss"""
+    import lidog_amd
+    from lidog_amd import synth
+    from lidog_amd.trainer import FlatAdam, SourceStep
+    torch.manual_seed(0)
+    model = lidog_amd.MinkUNet34(1, 7, 3).cuda().train()
+    step = SourceStep(model, FlatAdam(model, lr=1e-2, weight_decay=1e-4))
+    if name == "c1_source8k":
+        batch = synth.make_batch(range(4), "source8k", "cuda")
+    else:
+        batch = synth.make_batch(range(2), "nusc35k", "cuda", mix3d=True)
+    losses = [float(step.training_step(batch)["loss"]) for _ in range(8)]
+    # labels are uniform random per voxel (hard to fit): the loss only has to move down from its start
+    assert all(np.isfinite(losses)) and min(losses[-2:]) < losses[0] - 0.005, losses
+
+
+def test_lidog_training_config_learns():
+    """configs[1]: MinkUNet34BEV + BEV head at B = 50 m, bs 2 here"""
+    import lidog_amd
+    from lidog_amd import synth
+    from lidog_amd.trainer import FlatAdam, LiDOGStep
+    torch.manual_seed(0)
+    model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=50.0).cuda().train()
+    step = LiDOGStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4))
+    batch = synth.make_batch(range(2), "kitti120k", "cuda")
+    losses = [float(step.training_step(batch)["loss"]) for _ in range(5)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_highres_stress_forward():
+    """configs[4]: 524 288 points at 0.02 m voxels (~420 k active voxels), bs 1: maximum sizes run end to end"""
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    torch.manual_seed(0)
+    model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=50.0).cuda().train()
+    b = synth.make_batch([0], "highres524k", "cuda")
+    assert b["coords_int"].shape[0] > 400000
+    sem, bev = model(ME.SparseTensor(coordinates=b["coords_int"], features=b["source_features0"]), is_train=True)
+    assert sem.F.shape == (b["coords_int"].shape[0], 7) and tuple(bev["block8"].shape) == (1, 7, 167, 167)
+    assert torch.isfinite(sem.F).all() and torch.isfinite(bev["block8"]).all()
+    (sem.F.square().mean() + bev["block8"].square().mean()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
