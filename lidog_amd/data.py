@@ -116,3 +116,16 @@ def bev_labels(coords, labels, bound=50.0, img_size=167, voxel=0.05):
     call("lidog_bev_label_raster", ptr(coords), ptr(lab), coords.shape[0], ptr(lx), ptr(ly), ptr(lz), lo, lx.shape[0],
          B, S, ptr(start), ptr(pidx), ptr(img))
     return img, pidx
+
+
+def mix3d_merge(scan0, scan1, voxel_size=0.05, ignore_label=-1):
+    """Mix3DSourceDataset.merge_data (utils/datasets/mix3D.py:44-87): union of two voxelised scans, re-quantised.
+    scan = dict(coordinates int [n,3], features [n,C], sem_labels [n]) on the GPU.  As in the reference the
+    coordinates go through float32 (`coordinates * voxel_size`, then floor(x / voxel_size)), and the label of a
+    merged voxel is the label of its FIRST point (the voted labels returned by sparse_quantize are discarded)."""
+    coords = torch.cat([scan0["coordinates"], scan1["coordinates"]], dim=0).float() * voxel_size
+    feats = torch.cat([scan0["features"], scan1["features"]], dim=0)
+    labels = torch.cat([scan0["sem_labels"], scan1["sem_labels"]], dim=0)
+    q, _, _, idx = sparse_quantize(coords, feats, labels=labels, ignore_label=ignore_label,
+                                   quantization_size=voxel_size, return_index=True)
+    return {"coordinates": q, "features": feats[idx], "sem_labels": labels[idx], "index": idx}

@@ -64,3 +64,29 @@ def test_bev_label_rasteriser_matches_reference_golden(bound, size):
     i1 = idx[1].cpu().numpy()
     occ = i1 >= 0
     assert np.array_equal(img[1].cpu().numpy()[occ], labels[::-1][i1[occ]])
+
+
+def test_mix3d_merge_matches_reference_arithmetic():
+    """utils/datasets/mix3D.py:44-87 with the oracle's sparse_quantize: float32 round trip of the coordinates,
+    first-point labels"""
+    import oracle.me_cpu as OME
+    from lidog_amd.data import mix3d_merge
+    from lidog_amd import synth
+    a, la = synth.scan_voxels(4, "nusc35k")
+    b, lb = synth.scan_voxels(5, "nusc35k")
+    b[:200] = a[:200]                                   # guaranteed overlaps between the two scans
+    fa, fb = np.ones((a.shape[0], 1), np.float32), 2 * np.ones((b.shape[0], 1), np.float32)
+    coords = torch.cat([torch.from_numpy(a), torch.from_numpy(b)]) * 0.05      # int32 * float -> float32
+    feats = torch.cat([torch.from_numpy(fa), torch.from_numpy(fb)])
+    labels = torch.cat([torch.from_numpy(la), torch.from_numpy(lb)])
+    q, _, _, idx = OME.utils.sparse_quantize(coords.numpy(), feats.numpy(), labels=labels.numpy(), ignore_label=-1,
+                                             quantization_size=0.05, return_index=True)
+    got = mix3d_merge({"coordinates": torch.from_numpy(a).cuda(), "features": torch.from_numpy(fa).cuda(),
+                       "sem_labels": torch.from_numpy(la).cuda()},
+                      {"coordinates": torch.from_numpy(b).cuda(), "features": torch.from_numpy(fb).cuda(),
+                       "sem_labels": torch.from_numpy(lb).cuda()})
+    assert np.array_equal(got["coordinates"].cpu().numpy(), q)
+    assert np.array_equal(got["index"].cpu().numpy(), idx)
+    assert torch.equal(got["sem_labels"].cpu(), labels[torch.from_numpy(idx)])
+    assert torch.equal(got["features"].cpu(), feats[torch.from_numpy(idx)])
+    assert q.shape[0] < a.shape[0] + b.shape[0]

@@ -327,3 +327,20 @@ def test_iou_definition_matches_sklearn_as_the_reference_calls_it():
     m = np.stack(ref_rows)
     m[m == -1] = np.nan
     assert np.allclose(per_class.numpy(), np.nanmean(m, axis=0) * 100) and abs(float(mean) - np.nanmean(np.nanmean(m, axis=0) * 100)) < 1e-9
+
+
+def test_lightning_checkpoint_round_trip(tmp_path):
+    import lidog_amd
+    from lidog_amd.checkpoint import load_lightning_checkpoint, save_lightning_checkpoint, model_state_dict
+    m = lidog_amd.MinkUNet34(1, 7, 3)
+    sd = seeded_state_dict(m, seed=9)
+    m.load_state_dict(sd)
+    path = str(tmp_path / "epoch=4-step=100.ckpt")
+    save_lightning_checkpoint(m, path, epoch=4, global_step=100)
+    raw = torch.load(path, weights_only=False)
+    assert all(k.startswith("model.") for k in raw["state_dict"])           # the key layout Lightning writes
+    assert "model.block1.0.conv1.kernel" in raw["state_dict"] and "model.bn0.bn.running_var" in raw["state_dict"]
+    m2 = lidog_amd.MinkUNet34(1, 7, 3)
+    epoch, _ = load_lightning_checkpoint(m2, path)
+    assert epoch == 4 and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert set(model_state_dict(raw)) == set(sd)
