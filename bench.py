@@ -111,9 +111,17 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # test hooks only: LIDOG_BENCH_ONE_GPU=1 runs every rank on cuda:0 over gloo so the multi-rank control flow
+    # (SyncBN conversion, gradient buckets, barriers, max-over-ranks) can be exercised on a 1-GPU box
+    one_gpu = os.environ.get("LIDOG_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import lidog_amd

@@ -284,6 +284,47 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
     }
 }
 
+// [rows, C] layout, C % 4 == 0: 16-B accesses; the per-channel constants (m0, m1, invstd*w) are computed once
+// per thread, outside the row loop (each thread keeps its channel quad: the grid stride is a multiple of C4)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float4 *__restrict__ dy, const float4 *__restrict__ x,
+                                                       const float4 *__restrict__ ry, int64_t total4, int C4,
+                                                       const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd, const float *__restrict__ w,
+                                                       const double *__restrict__ sums, double inv_count,
+                                                       float4 *__restrict__ dx, float4 *__restrict__ dres) {
+    const int C = C4 * 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;  // launcher makes this a multiple of C4
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = (int)(i % C4);
+    const double ic = (inv_count > 0) ? inv_count : 1.0 / sums[2 * C];
+    float mu[4], is[4], sc[4], m0[4], m1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = c4 * 4 + j;
+        mu[j] = mean[c];
+        is[j] = invstd[c];
+        sc[j] = is[j] * w[c];
+        m0[j] = (float)(sums[c] * ic);
+        m1[j] = (float)(sums[C + c] * ic);
+    }
+    for (; i < total4; i += stride) {
+        float4 g = dy[i], xv = x[i];
+        if (ry) {
+            float4 y = ry[i];
+            g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+            g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        float4 o;
+        o.x = (g.x - m0[0] - (xv.x - mu[0]) * is[0] * m1[0]) * sc[0];
+        o.y = (g.y - m0[1] - (xv.y - mu[1]) * is[1] * m1[1]) * sc[1];
+        o.z = (g.z - m0[2] - (xv.z - mu[2]) * is[2] * m1[2]) * sc[2];
+        o.w = (g.w - m0[3] - (xv.w - mu[3]) * is[3] * m1[3]) * sc[3];
+        dx[i] = o;
+        if (dres) dres[i] = g;
+    }
+}
+
 __global__ void k_bn_param_grads(const double *__restrict__ sums, int C, float *dw, float *db) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -297,7 +338,21 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
                                   void *stream) {
     hipStream_t st = (hipStream_t)stream;
     int64_t total = n * C * hw;
-    if (total > 0)
+    if (total > 0 && hw == 1 && C % 4 == 0) {
+        int C4 = C / 4;
+        int64_t total4 = total / 4;
+        // grid stride = blocks * 256 must be a multiple of C4: blocks a multiple of C4 / gcd(C4, 256)
+        int g = C4;
+        for (int a = 256, b = C4; b;) { int t = a % b; a = b; b = t; g = a; }
+        int unit = C4 / g;
+        int64_t blocks = cdiv64(total4, 256 * 4);
+        if (blocks > 4096) blocks = 4096;
+        blocks = cdiv64(blocks, unit) * unit;
+        k_bn_bwd_apply4<<<(unsigned)blocks, 256, 0, st>>>((const float4 *)dy, (const float4 *)x,
+                                                          (const float4 *)relu_y, total4, C4, mean, invstd, w, sums,
+                                                          count > 0 ? 1.0 / count : -1.0, (float4 *)dx,
+                                                          (float4 *)dres);
+    } else if (total > 0)
         k_bn_bwd_apply<<<ew_grid(total), 256, 0, st>>>(dy, x, relu_y, total, C, hw, mean, invstd, w, sums,
                                                        count > 0 ? 1.0 / count : -1.0,
                                                        dx, dres);

@@ -265,6 +265,17 @@ class _ReLUFn(torch.autograd.Function):
         return dx, None
 
 
+def _grad_out(param, shape):
+    """Fresh view into the optimiser's flat gradient buffer for `param` (lidog_amd.trainer.FlatParams), or None.
+    A backward kernel that writes its parameter gradient there and returns the view lets autograd adopt it as
+    param.grad without the `grad += new` pass (one extra kernel per parameter per step otherwise)."""
+    ref = getattr(param, "_flat_ref", None)
+    if ref is None or param.grad is not None:
+        return None
+    buf, off = ref
+    return buf[off:off + param.numel()].view(shape)
+
+
 def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter):
     call("lidog_sconv_gemm", ptr(A), ptr(gather), ptr(B), ptr(bias), ptr(m.tiles[0]), ptr(m.tiles[1]),
          ptr(m.tiles[2]), m.n_tiles, Cin, Cout, ptr(out), ptr(scatter))
@@ -324,6 +335,7 @@ class _SparseConvFn(torch.autograd.Function):
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
         ctx.save_for_backward(x, W3)
         ctx.m, ctx.swap, ctx.single_in, ctx.has_bias, ctx.w_shape = m, swap, single_in, bias is not None, W.shape
+        ctx.w_param = W
         return out
 
     @staticmethod
@@ -354,7 +366,9 @@ class _SparseConvFn(torch.autograd.Function):
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(gx))
         if ctx.needs_input_grad[1]:
-            gW = torch.empty_like(W3)
+            gW = _grad_out(ctx.w_param, W3.shape)
+            if gW is None:
+                gW = torch.empty_like(W3)
             ns = _wgrad_splits(K, Cin, Cout, m.P)
             slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, ns)
             partial = torch.empty((slabs, K, Cin, Cout), dtype=torch.float32, device=x.device) if slabs > 1 else None
@@ -407,6 +421,7 @@ class _BatchNormFn(torch.autograd.Function):
              1 if relu else 0, ptr(y))
         ctx.save_for_backward(x, weight, mean, invstd, y if relu else None, count_t)
         ctx.cfg = (n, C, hw, count, training, residual is not None, group)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -419,17 +434,26 @@ class _BatchNormFn(torch.autograd.Function):
         call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums))
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        # parameter gradients come from the LOCAL sums (DDP averages them afterwards)
-        db = sums[:C].float()
-        dw = sums[C:2 * C].float()
-        if not training:
-            sums.zero_()  # running statistics are constants: dx = dy' * w * invstd
-        elif group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=group)
-            sums[2 * C:] = count_t
-        call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(sums),
-             count, ptr(dx), ptr(dres), None, None)
+        # parameter gradients come from the LOCAL sums (DDP averages them afterwards); they are written
+        # straight into the optimiser's flat gradient buffer when there is one
+        dw = _grad_out(ctx.params[0], (C,))
+        db = _grad_out(ctx.params[1], (C,))
+        dw = dw if dw is not None else torch.empty(C, dtype=torch.float32, device=dev)
+        db = db if db is not None else torch.empty(C, dtype=torch.float32, device=dev)
+        if training and group is None:
+            call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
+                 ptr(sums), count, ptr(dx), ptr(dres), ptr(dw), ptr(db))
+        else:
+            db.copy_(sums[:C])
+            dw.copy_(sums[C:2 * C])
+            if not training:
+                sums.zero_()  # running statistics are constants: dx = dy' * w * invstd
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(sums, group=group)
+                sums[2 * C:] = count_t
+            call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
+                 ptr(sums), count, ptr(dx), ptr(dres), None, None)
         return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
 
 

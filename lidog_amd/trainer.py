@@ -35,14 +35,34 @@ class FlatParams:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            p._flat_ref = (self.grad, off)   # lets backward kernels write this gradient in place (me._grad_out)
             self.offsets.append(off)
             off += n
         self.total = total
 
     def zero_grad(self):
+        """set_to_none semantics: backward kernels write fresh views of the flat buffer and autograd adopts them
+        as .grad, so there is no `grad += new` pass; the buffer is cleared for parameters that get no gradient"""
         self.grad.zero_()
-        for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad; point it back
-            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
+
+    def in_place(self, p, off):
+        return p.grad is not None and p.grad.data_ptr() == self.grad.data_ptr() + 4 * off
+
+    def gather_strays(self):
+        """gradients that autograd produced outside the flat buffer (e.g. a bias gradient from a torch op) are
+        copied in with one fused call; returns how many there were"""
+        dst, src = [], []
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is not None and not self.in_place(p, off):
+                view = self.grad[off:off + p.numel()].view(p.shape)
+                dst.append(view)
+                src.append(p.grad)
+                p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return len(dst)
 
 
 class GradientBuckets:
@@ -56,6 +76,7 @@ class GradientBuckets:
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handles = []
+        self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         self.bucket_of = {}
         self.pending0 = []
         self.slices = []
@@ -85,6 +106,11 @@ class GradientBuckets:
             self.bucket_of[id(p)] = b
 
     def _hook(self, p):
+        off = self.flat.offsets[self.index_of[id(p)]]
+        if not self.flat.in_place(p, off):   # stray gradient: bring it into the flat buffer before it is reduced
+            view = self.flat.grad[off:off + p.numel()].view(p.shape)
+            view.copy_(p.grad)
+            p.grad = view
         b = self.bucket_of[id(p)]
         self.pending[b] -= 1
         if self.pending[b] == 0:
@@ -122,6 +148,7 @@ class FlatAdam:
         self.flat.zero_grad()
 
     def step(self):
+        self.strays = self.flat.gather_strays()
         self.buckets.finish()
         self.steps += 1
         scale = 1.0 / self.buckets.world
