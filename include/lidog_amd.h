@@ -100,14 +100,17 @@ int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C);
 int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
                              float *out, double *sums, double *partial_ws, void *stream);
 
-/* gW[k] = sum over pairs p of segment k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
- * partial: float[n_split * K * Cin * Cout] workspace; the split partials are summed in split order. */
+/* gW[k] = sum over the pairs p of offset k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
+ * The pair list is cut on the host into work items of (nearly) equal length that never straddle an offset:
+ * items [3, n_items] int32 = (k, first pair, end pair), ordered by k; item_off [K+1] = first item of every k.
+ * Every item writes its own partial [Cin,Cout] slot(s); the slots of one offset are then summed in order.
+ * partial: lidog_sconv_wgrad_slabs(Cin, Cout, n_items) * Cin * Cout floats. */
 int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
-                      const int64_t *k_off_dev, int32_t K, int32_t Cin, int32_t Cout, int32_t n_split,
-                      float *partial, float *gW, void *stream);
+                      const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K, int32_t Cin,
+                      int32_t Cout, float *partial, float *gW, void *stream);
 
-/* slabs of K*Cin*Cout floats that `partial` must hold for lidog_sconv_wgrad with this n_split (>= n_split) */
-int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_split);
+/* slots of Cin*Cout floats that `partial` must hold for lidog_sconv_wgrad with n_items work items */
+int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_items);
 
 /* Arithmetic core of lidog_sconv_gemm / lidog_sconv_wgrad: 1 = exact-f32 MFMA (default), 0 = vector FMA.
  * Both produce bit-identical results (an f32 MFMA is a k-ordered fmaf chain); kept selectable for A/B. */

@@ -394,20 +394,16 @@ extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int6
 template <int RM, int CN>
 __global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A, const int32_t *__restrict__ pa,
                                                      const float *__restrict__ G, const int32_t *__restrict__ pg,
-                                                     const int64_t *__restrict__ k_off, int K, int Cin, int Cout,
-                                                     int n_split, float *__restrict__ partial) {
+                                                     const int32_t *__restrict__ items, int n_items, int Cin,
+                                                     int Cout, float *__restrict__ partial) {
     constexpr int TM = 16 * RM, TN = 16 * CN;
     __shared__ __attribute__((aligned(16))) float As[WG_R * TM];
     __shared__ __attribute__((aligned(16))) float Gs[WG_R * TN];
-    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    const int item = blockIdx.x;  // (offset, pair range) work item, equal-length ranges (see sconv_mfma.hip)
     const int tiles_n = Cout / TN;
     const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
-    const int64_t len = seg1 - seg0;
-    const int64_t per = ((len + n_split - 1) / n_split + WG_R - 1) / WG_R * WG_R;
-    const int64_t p0 = seg0 + (int64_t)split * per;
-    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
 
     float acc[RM][CN];
 #pragma unroll
@@ -498,7 +494,7 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad(const float *__restrict__ A
                 for (int j = 0; j < CN; ++j) acc[i][j] = __builtin_fmaf(a[i], g[j], acc[i][j]);
         }
     }
-    float *dst = partial + ((size_t)split * K + k) * Cin * Cout;
+    float *dst = partial + (size_t)item * Cin * Cout;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
         float *row = dst + (size_t)(ci0 + ty * RM + i) * Cout + co0;
@@ -518,19 +514,16 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_small(const float *__restri
                                                            const int32_t *__restrict__ pa,
                                                            const float *__restrict__ G,
                                                            const int32_t *__restrict__ pg,
-                                                           const int64_t *__restrict__ k_off, int K, int Cin,
-                                                           int Cout, int n_split, float *__restrict__ partial) {
-    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
-    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
-    const int64_t per = (seg1 - seg0 + n_split - 1) / n_split;
-    const int64_t p0 = seg0 + (int64_t)split * per;
-    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+                                                           const int32_t *__restrict__ items, int n_items,
+                                                           int Cin, int Cout, float *__restrict__ partial) {
+    const int item = blockIdx.x;
+    const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
     for (int e = blockIdx.y * 256 + threadIdx.x; e < Cin * Cout; e += 256 * gridDim.y) {
         int ci = e / Cout, co = e % Cout;
         float acc = 0.f;
         for (int64_t p = p0; p < p1; ++p)
             acc = __builtin_fmaf(A[(size_t)pa[p] * Cin + ci], G[(size_t)pg[p] * Cout + co], acc);
-        partial[((size_t)split * K + k) * Cin * Cout + e] = acc;
+        partial[(size_t)item * Cin * Cout + e] = acc;
     }
 }
 
@@ -540,14 +533,11 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cin1(const float *__restric
                                                           const int32_t *__restrict__ pa,
                                                           const float *__restrict__ G,
                                                           const int32_t *__restrict__ pg,
-                                                          const int64_t *__restrict__ k_off, int K, int Cout,
-                                                          int n_split, float *__restrict__ partial) {
+                                                          const int32_t *__restrict__ items, int n_items,
+                                                          int Cout, float *__restrict__ partial) {
     __shared__ float red[256];
-    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
-    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
-    const int64_t per = (seg1 - seg0 + n_split - 1) / n_split;
-    const int64_t p0 = seg0 + (int64_t)split * per;
-    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    const int item = blockIdx.x;
+    const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
     const int c = threadIdx.x % Cout, r = threadIdx.x / Cout, RL = 256 / Cout;
     float acc0 = 0.f, acc1 = 0.f;
     if (r < RL) {
@@ -565,7 +555,7 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cin1(const float *__restric
     if (r == 0) {
         float s = red[c];
         for (int rr = 1; rr < RL; ++rr) s += red[rr * Cout + c];
-        partial[((size_t)split * K + k) * Cout + c] = s;
+        partial[(size_t)item * Cout + c] = s;
     }
 }
 
@@ -574,14 +564,11 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cout8(const float *__restri
                                                            const int32_t *__restrict__ pa,
                                                            const float *__restrict__ G,
                                                            const int32_t *__restrict__ pg,
-                                                           const int64_t *__restrict__ k_off, int K, int Cin,
-                                                           int Cout, int n_split, float *__restrict__ partial) {
+                                                           const int32_t *__restrict__ items, int n_items,
+                                                           int Cin, int Cout, float *__restrict__ partial) {
     __shared__ float red[8 * 256];
-    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
-    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
-    const int64_t per = (seg1 - seg0 + n_split - 1) / n_split;
-    const int64_t p0 = seg0 + (int64_t)split * per;
-    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    const int item = blockIdx.x;
+    const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
     const int ci = threadIdx.x % Cin, r = threadIdx.x / Cin, RL = 256 / Cin;
     float acc[8];
 #pragma unroll
@@ -602,18 +589,36 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cout8(const float *__restri
         for (int j = 0; j < Cout; ++j) {
             float s = red[j * 256 + ci];
             for (int rr = 1; rr < RL; ++rr) s += red[j * 256 + rr * Cin + ci];
-            partial[(((size_t)split * K + k) * Cin + ci) * Cout + j] = s;
+            partial[((size_t)item * Cin + ci) * Cout + j] = s;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_split_sum(const float *__restrict__ partial, int64_t n, int n_split,
+// gW[k][e] = sum of the partial slots of the work items of offset k (item_off[k] .. item_off[k+1]), `per` slots
+// per item.  64 elements x 4 slot lanes per workgroup; each lane adds every 4th slot in order, the four lane sums
+// are combined in lane order (deterministic).
+__global__ __launch_bounds__(256) void k_items_sum(const float *__restrict__ partial,
+                                                   const int32_t *__restrict__ item_off, int per, int64_t n,
                                                    float *__restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float acc = partial[i];
-    for (int s = 1; s < n_split; ++s) acc += partial[(int64_t)s * n + i];
-    out[i] = acc;
+    __shared__ float red[256];
+    const int lane_e = threadIdx.x & 63, lane_s = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane_e;
+    const int k = blockIdx.y;
+    const int64_t s0 = (int64_t)item_off[k] * per, s1 = (int64_t)item_off[k + 1] * per;
+    float acc = 0.f;
+    if (e < n) {
+        int64_t sl = s0 + lane_s;
+        float a0 = 0.f, a1 = 0.f;  // two independent chains keep two loads in flight
+        for (; sl + 4 < s1; sl += 8) {
+            a0 += partial[sl * n + e];
+            a1 += partial[(sl + 4) * n + e];
+        }
+        if (sl < s1) a0 += partial[sl * n + e];
+        acc = a0 + a1;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane_s == 0 && e < n) out[(int64_t)k * n + e] = ((red[lane_e] + red[64 + lane_e]) + red[128 + lane_e]) + red[192 + lane_e];
 }
 
 static int pick_tile(int C) {
@@ -626,64 +631,57 @@ static int pick_tile(int C) {
 
 template <int RM>
 static void launch_wgrad_rm(int cn, dim3 grid, hipStream_t st, const float *A, const int32_t *pa, const float *G,
-                            const int32_t *pg, const int64_t *k_off, int K, int Cin, int Cout, int n_split,
+                            const int32_t *pg, const int32_t *items, int n_items, int Cin, int Cout,
                             float *partial) {
     switch (cn) {
-        case 8: k_sconv_wgrad<RM, 8><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial); break;
-        case 6: k_sconv_wgrad<RM, 6><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial); break;
-        case 4: k_sconv_wgrad<RM, 4><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial); break;
-        default: k_sconv_wgrad<RM, 2><<<grid, 256, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial);
+        case 8: k_sconv_wgrad<RM, 8><<<grid, 256, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout, partial); break;
+        case 6: k_sconv_wgrad<RM, 6><<<grid, 256, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout, partial); break;
+        case 4: k_sconv_wgrad<RM, 4><<<grid, 256, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout, partial); break;
+        default: k_sconv_wgrad<RM, 2><<<grid, 256, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout, partial);
     }
 }
 
-// number of [K,Cin,Cout] slabs the caller must provide in `partial` for a given split count
-extern "C" int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_split) {
-    if (g_sparse_core == 1 && pick_tile(Cin) && pick_tile(Cout)) return lidog_wgrad_mfma_slabs(Cin, Cout, n_split);
-    return n_split;
+// number of Cin*Cout-float slots the caller must provide in `partial` for n_items work items
+extern "C" int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_items) {
+    if (g_sparse_core == 1 && pick_tile(Cin) && pick_tile(Cout)) return lidog_wgrad_mfma_slabs(Cin, Cout, n_items);
+    return n_items;
 }
 
 extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
-                                 const int64_t *k_off_dev, int32_t K, int32_t Cin, int32_t Cout, int32_t n_split,
-                                 float *partial, float *gW, void *stream) {
+                                 const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K,
+                                 int32_t Cin, int32_t Cout, float *partial, float *gW, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    LIDOG_REQUIRE(n_split >= 1 && K >= 1, "sconv_wgrad: bad n_split/K");
+    LIDOG_REQUIRE(K >= 1 && n_items >= 0, "sconv_wgrad: bad K / n_items");
+    LIDOG_REQUIRE(n_items == 0 || partial != nullptr, "sconv_wgrad: partial workspace missing");
     int rm = pick_tile(Cin), cn = pick_tile(Cout);
-    if (g_sparse_core == 1 && rm && cn) {
-        int slabs = lidog_wgrad_mfma_slabs(Cin, Cout, n_split);
-        LIDOG_REQUIRE(slabs == 1 || partial != nullptr, "sconv_wgrad: partial workspace needed for %d slabs", slabs);
-        lidog_launch_wgrad_mfma(A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, slabs == 1 ? gW : partial, st);
-        if (slabs > 1) {
-            int64_t n = (int64_t)K * Cin * Cout;
-            k_split_sum<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(partial, n, slabs, gW);
+    int per = 1;
+    if (n_items > 0) {
+        if (g_sparse_core == 1 && rm && cn) {
+            per = lidog_wgrad_mfma_slabs(Cin, Cout, 1);
+            lidog_launch_wgrad_mfma(A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial, st);
+        } else if (rm && cn) {
+            dim3 grid((unsigned)n_items, (unsigned)((Cin / (16 * rm)) * (Cout / (16 * cn))));
+            switch (rm) {
+                case 8: launch_wgrad_rm<8>(cn, grid, st, A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial); break;
+                case 6: launch_wgrad_rm<6>(cn, grid, st, A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial); break;
+                case 4: launch_wgrad_rm<4>(cn, grid, st, A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial); break;
+                default: launch_wgrad_rm<2>(cn, grid, st, A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial);
+            }
+        } else if (Cin == 1 && Cout <= 256) {
+            k_sconv_wgrad_cin1<<<dim3((unsigned)n_items), 256, 0, st>>>(A, pair_a, G, pair_g, items, n_items, Cout,
+                                                                        partial);
+        } else if (Cout <= 8 && Cin <= 256) {
+            k_sconv_wgrad_cout8<<<dim3((unsigned)n_items), 256, 0, st>>>(A, pair_a, G, pair_g, items, n_items, Cin,
+                                                                         Cout, partial);
+        } else {
+            int by = (Cin * Cout + 255) / 256;
+            if (by > 64) by = 64;
+            k_sconv_wgrad_small<<<dim3((unsigned)n_items, (unsigned)by), 256, 0, st>>>(A, pair_a, G, pair_g, items,
+                                                                                      n_items, Cin, Cout, partial);
         }
-        LIDOG_LAUNCH_CHECK();
-        return 0;
     }
-    float *dst = (n_split == 1) ? gW : partial;
-    if (rm && cn) {
-        dim3 grid((unsigned)(K * n_split), (unsigned)((Cin / (16 * rm)) * (Cout / (16 * cn))));
-        switch (rm) {
-            case 8: launch_wgrad_rm<8>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
-            case 6: launch_wgrad_rm<6>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
-            case 4: launch_wgrad_rm<4>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst); break;
-            default: launch_wgrad_rm<2>(cn, grid, st, A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst);
-        }
-    } else if (Cin == 1 && Cout <= 256) {
-        k_sconv_wgrad_cin1<<<dim3((unsigned)(K * n_split)), 256, 0, st>>>(A, pair_a, G, pair_g, k_off_dev, K, Cout,
-                                                                          n_split, dst);
-    } else if (Cout <= 8 && Cin <= 256) {
-        k_sconv_wgrad_cout8<<<dim3((unsigned)(K * n_split)), 256, 0, st>>>(A, pair_a, G, pair_g, k_off_dev, K, Cin,
-                                                                           Cout, n_split, dst);
-    } else {
-        int by = (Cin * Cout + 255) / 256;
-        if (by > 64) by = 64;
-        k_sconv_wgrad_small<<<dim3((unsigned)(K * n_split), (unsigned)by), 256, 0, st>>>(
-            A, pair_a, G, pair_g, k_off_dev, K, Cin, Cout, n_split, dst);
-    }
-    if (n_split > 1) {
-        int64_t n = (int64_t)K * Cin * Cout;
-        k_split_sum<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(partial, n, n_split, gW);
-    }
+    int64_t n = (int64_t)Cin * Cout;
+    k_items_sum<<<dim3((unsigned)cdiv64(n, 64), (unsigned)K), 256, 0, st>>>(partial, item_off, per, n, gW);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

@@ -7,6 +7,5 @@ int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
                            int Cin, int Cout, float *T, const int32_t *scatter, hipStream_t st);
 int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, const int32_t *pg,
-                            const int64_t *k_off, int K, int Cin, int Cout, int n_split, float *partial,
-                            hipStream_t st);
-int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_split);
+                            const int32_t *items, int n_items, int Cin, int Cout, float *partial, hipStream_t st);
+int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_items);

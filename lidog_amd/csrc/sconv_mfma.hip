@@ -161,24 +161,23 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
                                                               const int32_t *__restrict__ pa,
                                                               const float *__restrict__ G,
                                                               const int32_t *__restrict__ pg,
-                                                              const int64_t *__restrict__ k_off, int K, int Cin,
-                                                              int Cout, int n_split, float *__restrict__ partial) {
+                                                              const int32_t *__restrict__ items, int n_items,
+                                                              int Cin, int Cout, float *__restrict__ partial) {
     constexpr int TM = 32 * MT, TN = 32 * NT, NTH = 64 * NW;
     constexpr int TILES = MT * NT;
     constexpr int WPG = NW / NGRP;            // waves per group
     constexpr int TPW = (TILES + WPG - 1) / WPG;  // tiles per wave
     __shared__ __attribute__((aligned(16))) float As[MW_R * TM];
     __shared__ __attribute__((aligned(16))) float Gs[MW_R * TN];
-    const int k = blockIdx.x / n_split, split = blockIdx.x % n_split;
+    // work item = (offset k, pair range [p0, p1)): ranges are cut to equal length on the host, so the offsets
+    // with many pairs (the centre offset owns one pair per voxel) get proportionally more workgroups
+    const int item = blockIdx.x;
     const int tiles_n = Cout / TN;
     const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int grp = wave / WPG, wig = wave % WPG;
-    const int64_t seg0 = k_off[k], seg1 = k_off[k + 1];
-    const int64_t per = ((seg1 - seg0 + n_split - 1) / n_split + MW_R - 1) / MW_R * MW_R;
-    const int64_t p0 = seg0 + (int64_t)split * per;
-    const int64_t p1 = (p0 + per < seg1) ? p0 + per : seg1;
+    const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
 
     int a_off[TPW], g_off[TPW];
     bool own[TPW];
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
                                                               0, 0, 0);
         }
     }
-    float *dst = partial + ((size_t)(split * NGRP + grp) * K + k) * Cin * Cout;
+    float *dst = partial + (size_t)(item * NGRP + grp) * Cin * Cout;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         if (!own[t]) continue;
@@ -297,24 +296,24 @@ static void wg_shape(int tiles, int *nw, int *ngrp) {
     }
 }
 
-int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_split) {
+int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_items) {
     int nw, ngrp;
     wg_shape(tile32(Cin) * tile32(Cout), &nw, &ngrp);
-    return n_split * ngrp;
+    return n_items * ngrp;
 }
 
 template <int MT, int NT, int NW, int NGRP>
 static void launch_wg(dim3 grid, hipStream_t st, const float *A, const int32_t *pa, const float *G, const int32_t *pg,
-                      const int64_t *k_off, int K, int Cin, int Cout, int n_split, float *partial) {
-    k_sconv_wgrad_mfma<MT, NT, NW, NGRP><<<grid, 64 * NW, 0, st>>>(A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial);
+                      const int32_t *items, int n_items, int Cin, int Cout, float *partial) {
+    k_sconv_wgrad_mfma<MT, NT, NW, NGRP><<<grid, 64 * NW, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout, partial);
 }
 
 int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, const int32_t *pg,
-                            const int64_t *k_off, int K, int Cin, int Cout, int n_split, float *partial,
+                            const int32_t *items, int n_items, int Cin, int Cout, float *partial,
                             hipStream_t st) {
     int mt = tile32(Cin), nt = tile32(Cout);
-    dim3 grid((unsigned)(K * n_split), (unsigned)((Cin / (32 * mt)) * (Cout / (32 * nt))));
-#define WG(MT_, NT_, NW_, NG_) launch_wg<MT_, NT_, NW_, NG_>(grid, st, A, pa, G, pg, k_off, K, Cin, Cout, n_split, partial)
+    dim3 grid((unsigned)n_items, (unsigned)((Cin / (32 * mt)) * (Cout / (32 * nt))));
+#define WG(MT_, NT_, NW_, NG_) launch_wg<MT_, NT_, NW_, NG_>(grid, st, A, pa, G, pg, items, n_items, Cin, Cout, partial)
     switch (mt * 10 + nt) {
         case 11: WG(1, 1, 4, 4); break;
         case 12: WG(1, 2, 4, 2); break;

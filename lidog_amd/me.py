@@ -281,19 +281,44 @@ def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter):
          ptr(m.tiles[2]), m.n_tiles, Cin, Cout, ptr(out), ptr(scatter))
 
 
-def _wgrad_splits(K, Cin, Cout, P):
+_WGRAD_TARGET_BLOCKS = 2048   # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X
+
+
+def _wgrad_items(m, Cin, Cout):
+    """Work items of the weight gradient: the rule book cut into pair ranges of equal length that never straddle
+    an offset (the centre offset of a 3^3 kernel owns one pair per voxel, corner offsets a few per cent of
+    that: equal splits per offset would leave most workgroups idle behind the centre ones).
+    Returns (items int32 [3, n] on the device, n, item_off int32 [K+1] on the device); cached on the map."""
     def tile(c):
         for t in (128, 96, 64, 32):
             if c % t == 0:
                 return t
         return c
     tiles = max(1, (Cin // tile(Cin)) * (Cout // tile(Cout)))
-    # The kernel is a latency-bound two-level gather (pair index -> feature row): throughput scales with the
-    # number of resident workgroups, so aim at ~16 per CU; partial slabs cost 4*K*Cin*Cout bytes each.
-    s = max(1, -(-4096 // (K * tiles)))
-    s = min(s, 512, max(1, P // (K * 128)))      # but at least 128 pairs (4 LDS stages) per split
-    s = min(s, max(1, (160 << 20) // (4 * K * Cin * Cout)))  # and at most 160 MB of partial slabs to re-read
-    return s
+    # measured on MI355X (scripts/sweep_wgrad.py): 8 workgroups per CU for the wide layers, 4 for the narrow ones
+    # (their partial slots are cheap to compute and the final slot sum dominates)
+    blocks = _WGRAD_TARGET_BLOCKS if Cin * Cout >= 128 * 128 else _WGRAD_TARGET_BLOCKS // 2
+    target = max(1, blocks // tiles)
+    chunk = max(128, -(-m.P // target))
+    max_items = max(1, (192 << 20) // (4 * Cin * Cout))             # at most ~192 MB of partial slots
+    chunk = max(chunk, -(-m.P // max_items))
+    chunk = (chunk + 31) // 32 * 32
+    key = chunk
+    cache = m.__dict__.setdefault("_wgrad_items", {})
+    if key not in cache:
+        k_off = np.asarray(m.k_off_host, dtype=np.int64)
+        cnt = np.diff(k_off)
+        n_k = (cnt + chunk - 1) // chunk
+        total = int(n_k.sum())
+        item_k = np.repeat(np.arange(len(cnt), dtype=np.int64), n_k)
+        first = np.repeat(np.cumsum(n_k) - n_k, n_k)
+        within = np.arange(total, dtype=np.int64) - first
+        p0 = k_off[item_k] + within * chunk
+        p1 = np.minimum(p0 + chunk, k_off[item_k + 1])
+        items = torch.from_numpy(np.stack([item_k, p0, p1]).astype(np.int32)).to(m.k_off.device)
+        item_off = torch.from_numpy(np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)).to(m.k_off.device)
+        cache[key] = (items, total, item_off)
+    return cache[key]
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -369,11 +394,11 @@ class _SparseConvFn(torch.autograd.Function):
             gW = _grad_out(ctx.w_param, W3.shape)
             if gW is None:
                 gW = torch.empty_like(W3)
-            ns = _wgrad_splits(K, Cin, Cout, m.P)
-            slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, ns)
-            partial = torch.empty((slabs, K, Cin, Cout), dtype=torch.float32, device=x.device) if slabs > 1 else None
-            call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(m.k_off), K, Cin, Cout, ns,
-                 ptr(partial), ptr(gW))
+            items, n_items, item_off = _wgrad_items(m, Cin, Cout)
+            slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, n_items)
+            partial = torch.empty((max(slabs, 1), Cin, Cout), dtype=torch.float32, device=x.device)
+            call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items, ptr(item_off),
+                 K, Cin, Cout, ptr(partial), ptr(gW))
             gW = gW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(dim=0, keepdim=True)

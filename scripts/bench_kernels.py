@@ -36,13 +36,13 @@ for s, k, Cin, Cout in cases:
     g = torch.randn(m.n_out, Cout, device="cuda"); Wt = W.transpose(1, 2).contiguous()
     T = torch.empty(m.P, Cout, device="cuda"); out = torch.empty(m.n_out, Cout, device="cuda")
     T2 = torch.empty(m.P, Cin, device="cuda"); gx = torch.empty(m.n_in, Cin, device="cuda"); gW = torch.empty_like(W)
-    ns = ME._wgrad_splits(m.K, Cin, Cout, m.P)
+    items, ns, item_off = ME._wgrad_items(m, Cin, Cout)
     slabs = L.lidog_sconv_wgrad_slabs(Cin, Cout, ns)
-    part = torch.empty(slabs, m.K, Cin, Cout, device="cuda") if slabs > 1 else None
+    part = torch.empty(max(slabs, 1), Cin, Cout, device="cuda")
     t_g = timeit(lambda: ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T, None))
     t_r = timeit(lambda: call("lidog_sconv_reduce", ptr(T), ptr(m.pos_out), m.n_out, m.K, Cout, None, ptr(out)))
     t_d = timeit(lambda: ME._gemm(g, m.pair_out, Wt, None, m, Cout, Cin, T2, None))
-    t_w = timeit(lambda: call("lidog_sconv_wgrad", ptr(x), ptr(m.pair_in), ptr(g), ptr(m.pair_out), ptr(m.k_off), m.K, Cin, Cout, ns, ptr(part), ptr(gW)))
+    t_w = timeit(lambda: call("lidog_sconv_wgrad", ptr(x), ptr(m.pair_in), ptr(g), ptr(m.pair_out), ptr(items), ns, ptr(item_off), m.K, Cin, Cout, ptr(part), ptr(gW)))
     fl = 2.0 * m.P * Cin * Cout / 1e9
     print("s%-2d k%d %3d->%3d ns=%-3d %9d | %8.3f %7.1f | %8.3f | %8.3f %7.1f | %8.3f %7.1f" % (s, k, Cin, Cout, ns, m.P, t_g, fl / t_g, t_r, t_d, fl / t_d, t_w, fl / t_w))
     for i, t in enumerate((t_g, t_r, t_d, t_w)): tot[i] += t

@@ -1,0 +1,15 @@
+"""training steps only (no eval / cpu baseline): the command profiled for profiles/*kernel_stats*"""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
+import torch, lidog_amd
+from lidog_amd import synth
+from lidog_amd.trainer import FlatAdam, LiDOGStep
+torch.manual_seed(1234)
+model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=50.0).cuda().train()
+step = LiDOGStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4))
+batches = [synth.make_batch(range(4 * i, 4 * i + 4), "kitti120k", "cuda") for i in range(2)]
+n = int(os.environ.get("STEPS", 5))
+for i in range(n):
+    step.training_step(batches[i % 2])
+torch.cuda.synchronize()
+print("steps", n)
