@@ -152,6 +152,19 @@ def cat(*tensors):
                         coordinate_map_key=key)
 
 
+def _gather(src, idx):
+    idx = idx.contiguous()
+    out = torch.empty((idx.shape[0], src.shape[1]), dtype=torch.float32)
+    lib().orc_gather_rows(_ptr(src), _ptr(idx), idx.shape[0], src.shape[1], _ptr(out))
+    return out
+
+
+def _scatter_add(dst, idx, rows):
+    idx, rows = idx.contiguous(), rows.contiguous()
+    lib().orc_scatter_add_rows(_ptr(rows), _ptr(idx), idx.shape[0], dst.shape[1], _ptr(dst))
+    return dst
+
+
 class _SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, k_off, pin, pout, n_out):
@@ -161,11 +174,11 @@ class _SparseConvFn(torch.autograd.Function):
         out = torch.zeros((n_out, Cout), dtype=torch.float32)
         if _MODE == "exact":
             lib().orc_conv_fwd(_ptr(x), _ptr(W), _ptr(k_off), _ptr(pin), _ptr(pout), K, Cin, Cout, _ptr(out))
-        else:
+        else:  # ME's CPU algorithm: per offset gather rows -> BLAS GEMM -> scatter-add rows (OpenMP helpers)
             for k in range(K):
                 a, b = int(k_off[k]), int(k_off[k + 1])
                 if b > a:
-                    out.index_add_(0, pout[a:b].long(), x[pin[a:b].long()] @ W[k])
+                    out = _scatter_add(out, pout[a:b], _gather(x, pin[a:b]) @ W[k])
         ctx.save_for_backward(x, W, k_off, pin, pout)
         return out
 
@@ -183,9 +196,9 @@ class _SparseConvFn(torch.autograd.Function):
             for k in range(K):
                 a, b = int(k_off[k]), int(k_off[k + 1])
                 if b > a:
-                    g = gout[pout[a:b].long()]
-                    xi = x[pin[a:b].long()]
-                    gin.index_add_(0, pin[a:b].long(), g @ W[k].t())
+                    g = _gather(gout, pout[a:b])
+                    xi = _gather(x, pin[a:b])
+                    gin = _scatter_add(gin, pin[a:b], g @ W[k].t())
                     gW[k] = xi.t() @ g
         return gin, gW, None, None, None, None
 

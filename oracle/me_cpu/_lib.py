@@ -35,6 +35,10 @@ def lib():
             f = getattr(L, name)
             f.restype = None
             f.argtypes = [p, p, p, p, p, i32, i32, i32, p]
+        for name in ("orc_gather_rows", "orc_scatter_add_rows"):
+            f = getattr(L, name)
+            f.restype = None
+            f.argtypes = [p, p, i64, i32, p]
         L.orc_sparse_quantize.restype = i64
         L.orc_sparse_quantize.argtypes = [p, i64, p, i32, p, p, p]
         _lib = L

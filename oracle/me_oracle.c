@@ -262,3 +262,20 @@ int64_t orc_sparse_quantize(const int32_t *vox, int64_t n, const int32_t *labels
     }
     return m;
 }
+
+/* Helpers of the "blas" mode of oracle/me_cpu (the timed CPU baseline): ME's CPU convolution gathers the input
+ * rows of one kernel offset into a dense buffer, calls a BLAS GEMM and scatter-adds the result rows.  Within one
+ * offset every output row occurs at most once, so the scatter-add is race-free across threads. */
+void orc_gather_rows(const float *src, const int32_t *idx, int64_t n, int32_t C, float *dst) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) memcpy(dst + i * C, src + (int64_t)idx[i] * C, sizeof(float) * (size_t)C);
+}
+
+void orc_scatter_add_rows(const float *src, const int32_t *idx, int64_t n, int32_t C, float *dst) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        float *d = dst + (int64_t)idx[i] * C;
+        const float *s = src + i * C;
+        for (int32_t c = 0; c < C; ++c) d[c] += s[c];
+    }
+}
