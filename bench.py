@@ -71,7 +71,7 @@ class GemmTimer:
         return dict(launches=len(self.records), total_ms=ms, bytes=by, flops=fl)
 
 
-def cpu_baseline(config, steps_budget_s=30.0):
+def cpu_baseline(config, steps_budget_s=30.0, threads=None):
     """The CPU oracle (ME-equivalent restatement, per-offset gather -> BLAS GEMM -> scatter-add) timed on
     this box's host cores on ONE scan of the same workload, full training step."""
     import oracle.me_cpu as OME
@@ -79,6 +79,12 @@ def cpu_baseline(config, steps_budget_s=30.0):
     from lidog_amd.minkunet import make_models
     from lidog_amd import synth
     OME.set_mode("blas")
+    # the layer GEMMs are small: past ~32 threads the two OpenMP runtimes (torch's and the oracle's) only fight
+    threads = threads or int(os.environ.get("LIDOG_CPU_BASELINE_THREADS", min(32, os.cpu_count() or 1)))
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    from oracle.me_cpu._lib import lib as _olib
+    _olib().orc_set_threads(threads)
     torch.manual_seed(0)
     cls = make_models(OME, Encoder2DRef, lambda x, bound, voxel, pool: sparse2super_ref(x.C, x.F, bound, voxel, pool))
     model = cls.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"],
@@ -101,7 +107,8 @@ def cpu_baseline(config, steps_budget_s=30.0):
             break
     dt = time.time() - t0
     OME.set_mode("exact")
-    return {"value": n / dt, "unit": "scans/s", "cores": torch.get_num_threads(), "kind": "port",
+    torch.set_num_threads(prev_threads)
+    return {"value": n / dt, "unit": "scans/s", "cores": threads, "kind": "port",
             "sample": f"{n} training step(s) of 1 synthetic {config} scan, MinkUNet34BEV B=50, oracle blas mode "
                       f"(per-offset gather->GEMM->scatter-add), {dt:.1f} s"}
 

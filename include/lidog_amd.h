@@ -93,8 +93,8 @@ int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, cons
 int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
                        float *out, void *stream);
 
-/* lidog_sconv_reduce with the BatchNorm statistics of `out` folded into the same pass: sums[0..C) += sum over
- * rows of out, sums[C..2C) += sum of squares (fp64, added in a fixed order: bit-reproducible).
+/* lidog_sconv_reduce with the BatchNorm statistics of `out` folded into the same pass: sums[0..C) = sum over
+ * rows of out, sums[C..2C) = sum of squares (fp64, added in a fixed order: bit-reproducible; overwritten).
  * partial_ws: lidog_sconv_reduce_stats_ws(n, C) doubles.  C % 4 == 0. */
 int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C);
 int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
@@ -125,8 +125,10 @@ int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout,
  * ME.MinkowskiReLU (:124).  layout: x[n, C] when hw == 1; NCHW with hw = H*W otherwise
  * (nn.BatchNorm2d of utils/models/conv2d.py:18,21). */
 
-/* per-channel sums in double: sums[2*C] = (sum x, sum x^2); accumulates into sums (zero it first) */
-int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, void *stream);
+/* per-channel sums in double: sums[2*C] = (sum x, sum x^2), overwritten.  ws: lidog_bn_reduce_ws(C, hw) doubles of
+ * scratch (per-workgroup partials added in a fixed order; 0 = not needed, ws may be NULL) */
+int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw);
+int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws, void *stream);
 /* mean/invstd from sums and count; updates running stats (momentum, unbiased var) when not NULL.
  * count <= 0: the count is read from sums[2*C] on the device (SyncBatchNorm all-reduces it with the sums);
  * the same convention holds for lidog_bn_bwd_apply. */
@@ -135,9 +137,9 @@ int lidog_bn_finalize(const double *sums, double count, int32_t C, float eps, fl
 /* y = (x - mean) * invstd * w + b (+ residual) (relu).  In-place (y == x) allowed. */
 int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean, const float *invstd,
                    const float *w, const float *b, const float *residual, int32_t relu, float *y, void *stream);
-/* backward reduce: sums[2*C] += (sum dy', sum dy'*xhat) with dy' = dy * (y > 0) when relu_y != NULL */
+/* backward reduce: sums[2*C] = (sum dy', sum dy'*xhat) with dy' = dy * (y > 0) when relu_y != NULL; ws as above */
 int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
-                        const float *mean, const float *invstd, double *sums, void *stream);
+                        const float *mean, const float *invstd, double *sums, double *ws, void *stream);
 /* dx = w*invstd*(dy' - s0/count - xhat*s1/count); dres = dy' when dres != NULL; dw = s1, db = s0 */
 int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                        const float *mean, const float *invstd, const float *w, const double *sums, double count,

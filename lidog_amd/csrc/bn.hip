@@ -27,7 +27,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict__ x, const float4 *__restrict__ dy,
                                                        const float4 *__restrict__ ry, int64_t n, int C4,
                                                        const float *__restrict__ mean,
-                                                       const float *__restrict__ invstd, double *__restrict__ sums) {
+                                                       const float *__restrict__ invstd,
+                                                       double *__restrict__ partial) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
     const int tid = threadIdx.x;
@@ -41,29 +42,33 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
     }
     if (active) {
         const int64_t step = (int64_t)gridDim.x * RB;
-        // 4 independent rows in flight per lane: the pass is a pure HBM/L2 stream
+        // 4 independent rows in flight per lane: the pass is a pure HBM/L2 stream.  Loads are unconditional
+        // (row clamped, value selected afterwards): a branch around a load costs a full wait per element
         for (int64_t row0 = (int64_t)blockIdx.x * RB + r; row0 < n; row0 += 4 * step) {
             float4 v[4], g[4], y[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int64_t row = row0 + u * step;
-                bool ok = row < n;
-                v[u] = ok ? x[row * C4 + c4] : make_float4(0, 0, 0, 0);
-                g[u] = make_float4(0, 0, 0, 0);
-                y[u] = make_float4(1, 1, 1, 1);
-                if (MODE == 1 && ok) {
+                row = row < n ? row : n - 1;
+                v[u] = x[row * C4 + c4];
+                if (MODE == 1) {
                     g[u] = dy[row * C4 + c4];
-                    if (ry) y[u] = ry[row * C4 + c4];
+                    y[u] = ry ? ry[row * C4 + c4] : make_float4(1, 1, 1, 1);
+                } else {
+                    g[u] = make_float4(0, 0, 0, 0);
+                    y[u] = make_float4(1, 1, 1, 1);
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (row0 + u * step < n) {
-                    red_terms<MODE>(v[u].x, g[u].x, y[u].x, ry != nullptr, m[0], is[0], a[0], a[4]);
-                    red_terms<MODE>(v[u].y, g[u].y, y[u].y, ry != nullptr, m[1], is[1], a[1], a[5]);
-                    red_terms<MODE>(v[u].z, g[u].z, y[u].z, ry != nullptr, m[2], is[2], a[2], a[6]);
-                    red_terms<MODE>(v[u].w, g[u].w, y[u].w, ry != nullptr, m[3], is[3], a[3], a[7]);
-                }
+                const bool ok = row0 + u * step < n;
+                const float4 z = make_float4(0, 0, 0, 0);
+                float4 vv = (MODE == 0 && !ok) ? z : v[u];
+                float4 gg = ok ? g[u] : z;
+                red_terms<MODE>(vv.x, gg.x, y[u].x, ry != nullptr, m[0], is[0], a[0], a[4]);
+                red_terms<MODE>(vv.y, gg.y, y[u].y, ry != nullptr, m[1], is[1], a[1], a[5]);
+                red_terms<MODE>(vv.z, gg.z, y[u].z, ry != nullptr, m[2], is[2], a[2], a[6]);
+                red_terms<MODE>(vv.w, gg.w, y[u].w, ry != nullptr, m[3], is[3], a[3], a[7]);
             }
         }
     }
@@ -75,12 +80,40 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
         for (int rr = 1; rr < RB; ++rr)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
+        // one partial row per workgroup, summed in block order by k_partials_sum: no atomics (512 workgroups
+        // adding to the same 2C addresses cost ~25 us of serialised L2 atomics), bit-reproducible
+        double *dst = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            atomic_add_f64(&sums[c4 * 4 + j], a[j]);
-            atomic_add_f64(&sums[C + c4 * 4 + j], a[4 + j]);
+            dst[c4 * 4 + j] = a[j];
+            dst[C + c4 * 4 + j] = a[4 + j];
         }
     }
+}
+
+// sums[c] = sum over blocks (ascending, fixed tree) of partial[b][c]; one workgroup per 4 channels
+__global__ __launch_bounds__(256) void k_partials_sum(const double *__restrict__ partial, int nb, int C2,
+                                                      double *__restrict__ sums) {
+    __shared__ double red[256];
+    const int cl = threadIdx.x & 3, bl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    double s0 = 0, s1 = 0;
+    if (c < C2) {
+        int b = bl;
+        for (; b + 64 < nb; b += 128) {
+            s0 += partial[(size_t)b * C2 + c];
+            s1 += partial[(size_t)(b + 64) * C2 + c];
+        }
+        if (b < nb) s0 += partial[(size_t)b * C2 + c];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (bl < d) red[threadIdx.x] += red[threadIdx.x + d * 4];
+        __syncthreads();
+    }
+    if (bl == 0 && c < C2) sums[c] = red[cl];
 }
 
 // generic layout (NCHW planes, or [n,C] with C % 4 != 0 as hw = 1 "planes" of strided access)
@@ -144,42 +177,54 @@ __global__ __launch_bounds__(256) void k_colreduce_strided(const float *__restri
     }
 }
 
+static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4 == 0 && C / 4 <= 256; }
+#define COLREDUCE_MAX_BLOCKS 512
+
 template <int MODE>
 static int launch_colreduce(const float *x, const float *dy, const float *ry, int64_t n, int C, int64_t hw,
-                            const float *mean, const float *invstd, double *sums, hipStream_t st) {
-    if (n == 0) return 0;
-    if (hw == 1) {
-        if (C % 4 == 0 && C / 4 <= 256) {
-            int C4 = C / 4, RB = 256 / C4;
-            // 2 workgroups per CU: enough loads in flight to stream, few enough that the 2*C double atomics
-            // per workgroup (all on the same 2*C addresses) stay off the critical path
-            int64_t nb = cdiv64(n, (int64_t)RB * 16);
-            if (nb > 512) nb = 512;
-            k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy,
-                                                                (const float4 *)ry, n, C4, mean, invstd, sums);
-        } else {
-            k_colreduce_strided<MODE><<<(unsigned)C, 256, 0, st>>>(x, dy, ry, n, C, mean, invstd, sums);
-        }
+                            const float *mean, const float *invstd, double *sums, double *ws, hipStream_t st) {
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) == hipSuccess ? 0 : 1;
+    if (colreduce_uses_partials(C, hw)) {
+        LIDOG_REQUIRE(ws != nullptr, "bn reduce: workspace of lidog_bn_reduce_ws() doubles required");
+        int C4 = C / 4, RB = 256 / C4;
+        // 2 workgroups per CU, 4 rows in flight per lane: enough loads in flight to stream
+        int64_t nb = cdiv64(n, (int64_t)RB * 16);
+        if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
+        k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
+                                                            n, C4, mean, invstd, ws);
+        k_partials_sum<<<(unsigned)cdiv64(2 * C, 4), 256, 0, st>>>(ws, (int)nb, 2 * C, sums);
     } else {
-        // n = number of images B; planes = B*C
-        int64_t planes = n * C;
-        int chunks = (int)cdiv64(hw, 16384);
-        if (chunks < 1) chunks = 1;
-        if (chunks > 64) chunks = 64;
-        k_colreduce_plane<MODE><<<dim3((unsigned)planes, (unsigned)chunks), 256, 0, st>>>(x, dy, ry, hw, C, mean, invstd,
-                                                                                          sums);
+        // atomic variants accumulate: start from zero
+        if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) return 1;
+        if (hw == 1) {
+            k_colreduce_strided<MODE><<<(unsigned)C, 256, 0, st>>>(x, dy, ry, n, C, mean, invstd, sums);
+        } else {
+            // n = number of images B; planes = B*C
+            int64_t planes = n * C;
+            int chunks = (int)cdiv64(hw, 16384);
+            if (chunks < 1) chunks = 1;
+            if (chunks > 64) chunks = 64;
+            k_colreduce_plane<MODE><<<dim3((unsigned)planes, (unsigned)chunks), 256, 0, st>>>(x, dy, ry, hw, C, mean,
+                                                                                              invstd, sums);
+        }
     }
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, void *stream) {
-    return launch_colreduce<0>(x, nullptr, nullptr, n, C, hw, nullptr, nullptr, sums, (hipStream_t)stream);
+extern "C" int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw) {
+    return colreduce_uses_partials(C, hw) ? (int64_t)COLREDUCE_MAX_BLOCKS * 2 * C : 0;
+}
+
+extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws,
+                              void *stream) {
+    return launch_colreduce<0>(x, nullptr, nullptr, n, C, hw, nullptr, nullptr, sums, ws, (hipStream_t)stream);
 }
 
 extern "C" int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C,
-                                   int64_t hw, const float *mean, const float *invstd, double *sums, void *stream) {
-    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, (hipStream_t)stream);
+                                   int64_t hw, const float *mean, const float *invstd, double *sums, double *ws,
+                                   void *stream) {
+    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, ws, (hipStream_t)stream);
 }
 
 __global__ void k_bn_finalize(const double *__restrict__ sums, double count, int C, float eps, float momentum,

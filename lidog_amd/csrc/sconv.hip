@@ -346,23 +346,30 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__res
     }
 }
 
-// one workgroup per 8 channels: 32 lanes stride over the partial blocks, then a fixed-order tree in LDS
+// one workgroup per 4 channels: 64 lanes stride over the partial blocks (two loads in flight), then a fixed-order
+// tree in LDS
 __global__ __launch_bounds__(256) void k_stats_finish(const double *__restrict__ partial, int nb, int C2,
                                                       double *__restrict__ sums) {
     __shared__ double red[256];
-    const int cl = threadIdx.x & 7, bl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
-    double s = 0;
-    if (c < C2)
-        for (int b = bl; b < nb; b += 32) s += partial[(size_t)b * C2 + c];
-    red[threadIdx.x] = s;
+    const int cl = threadIdx.x & 3, bl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
+    double s0 = 0, s1 = 0;
+    if (c < C2) {
+        int b = bl;
+        for (; b + 64 < nb; b += 128) {
+            s0 += partial[(size_t)b * C2 + c];
+            s1 += partial[(size_t)(b + 64) * C2 + c];
+        }
+        if (b < nb) s0 += partial[(size_t)b * C2 + c];
+    }
+    red[threadIdx.x] = s0 + s1;
     __syncthreads();
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) {
-        if (bl < d) red[threadIdx.x] += red[threadIdx.x + d * 8];
+    for (int d = 32; d >= 1; d >>= 1) {
+        if (bl < d) red[threadIdx.x] += red[threadIdx.x + d * 4];
         __syncthreads();
     }
-    if (bl == 0 && c < C2) sums[c] += red[cl];
+    if (bl == 0 && c < C2) sums[c] = red[cl];
 }
 
 extern "C" int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C) {
@@ -382,7 +389,7 @@ extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int6
     if (nb > 2048) nb = 2048;
     k_sconv_reduce4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, pos, n, K, C4, (const float4 *)bias,
                                                         (float4 *)out, partial_ws);
-    k_stats_finish<<<(unsigned)cdiv64(2 * C, 8), 256, 0, st>>>(partial_ws, (int)nb, 2 * C, sums);
+    k_stats_finish<<<(unsigned)cdiv64(2 * C, 4), 256, 0, st>>>(partial_ws, (int)nb, 2 * C, sums);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

@@ -350,7 +350,7 @@ class _SparseConvFn(torch.autograd.Function):
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
             _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
             if stats is not None and Cout % 4 == 0 and Cout <= 1024:
-                sums = torch.zeros(2 * Cout + 1, dtype=torch.float64, device=x.device)
+                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
                 ws = torch.empty(_lib.load().lidog_sconv_reduce_stats_ws(n_out, Cout), dtype=torch.float64,
                                  device=x.device)
                 call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
@@ -405,6 +405,12 @@ class _SparseConvFn(torch.autograd.Function):
         return gx, gW, gb, None, None, None, None, None
 
 
+def _bn_ws(C, hw, dev):
+    """scratch of the BatchNorm reductions (per-workgroup partials)"""
+    n = _lib.load().lidog_bn_reduce_ws(C, hw)
+    return torch.empty(n, dtype=torch.float64, device=dev) if n else None
+
+
 class _BatchNormFn(torch.autograd.Function):
     """BatchNorm over rows ([n,C], hw=1) or NCHW images (hw=H*W), optional fused residual add and ReLU.
     `group`: torch.distributed process group for SyncBatchNorm statistics (None = local).
@@ -424,8 +430,8 @@ class _BatchNormFn(torch.autograd.Function):
         count_t = None
         if training:
             if sums is None:
-                sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
-                call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums))
+                sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+                call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)))
             if group is not None:
                 # (sum x, sum x^2, rows) summed over the ranks in ONE message; the count stays on the device
                 import torch.distributed as dist
@@ -455,8 +461,9 @@ class _BatchNormFn(torch.autograd.Function):
         n, C, hw, count, training, has_res, group = ctx.cfg
         dy = dy.contiguous()
         dev = x.device
-        sums = torch.zeros(2 * C + 1, dtype=torch.float64, device=dev)
-        call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums))
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums),
+             ptr(_bn_ws(C, hw, dev)))
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         # parameter gradients come from the LOCAL sums (DDP averages them afterwards); they are written
@@ -482,11 +489,31 @@ class _BatchNormFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
 
 
+def _flush_batch_counter(bn, *_):
+    n = getattr(bn, "_nbt_pending", 0)
+    if n:
+        bn._nbt_pending = 0
+        bn.num_batches_tracked.add_(n)
+
+
+def _count_batch(bn):
+    """num_batches_tracked += 1 counted on the host (62 one-element kernel launches per step otherwise); the
+    buffer is brought up to date whenever a state_dict is taken."""
+    bn._nbt_pending = getattr(bn, "_nbt_pending", 0) + 1
+    if not getattr(bn, "_nbt_hooked", False):
+        bn._nbt_hooked = True
+        bn.register_state_dict_pre_hook(_flush_batch_counter)
+        bn.register_load_state_dict_pre_hook(lambda module, *_: setattr(module, "_nbt_pending", 0))
+
+
 def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, sums=None):
     """functional entry used by the modules below and by lidog_amd.bev"""
     training = bn.training or not bn.track_running_stats
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:  # cumulative average reads the counter: keep it exact on the device
+            bn.num_batches_tracked.add_(1)
+        else:
+            _count_batch(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                               hw, relu, residual, group, sums if training else None)

@@ -39,6 +39,8 @@ def lib():
             f = getattr(L, name)
             f.restype = None
             f.argtypes = [p, p, i64, i32, p]
+        L.orc_set_threads.restype = None
+        L.orc_set_threads.argtypes = [i32]
         L.orc_sparse_quantize.restype = i64
         L.orc_sparse_quantize.argtypes = [p, i64, p, i32, p, p, p]
         _lib = L

@@ -279,3 +279,10 @@ void orc_scatter_add_rows(const float *src, const int32_t *idx, int64_t n, int32
         for (int32_t c = 0; c < C; ++c) d[c] += s[c];
     }
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int32_t n) { omp_set_num_threads(n); }
+#else
+void orc_set_threads(int32_t n) { (void)n; }
+#endif
