@@ -154,8 +154,11 @@ int lidog_add(const float *a, const float *b, int64_t n, float *out, void *strea
 int lidog_bev_winner(const int32_t *coords, int64_t n, const int32_t *lut_x, const int32_t *lut_y, int32_t lut_lo,
                      int32_t lut_n, int32_t H, int32_t W, int32_t *winner /*[B,H,W], pre-filled -1*/,
                      int32_t *pixel /*[n] linear b*H*W+py*W+px or -1*/, void *stream);
-int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, int32_t B, int32_t H, int32_t W,
-                       int32_t pk, int32_t ps, int32_t pp, int32_t Ho, int32_t Wo, float *out /*[B,C,Ho,Wo]*/,
+/* winner/pixel/n: as produced by lidog_bev_winner for the same rows (only windows that contain a cell of an
+ * occupied pixel are computed; the rest of out/argsrc is filled with 0 / -1). */
+int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, const int32_t *pixel, int64_t n,
+                       int32_t B, int32_t H, int32_t W, int32_t pk, int32_t ps, int32_t pp, int32_t Ho, int32_t Wo,
+                       float *out /*[B,C,Ho,Wo]*/,
                        int32_t *argsrc /*[B,C,Ho,Wo] row*C+c of the arg-max cell or -1*/, void *stream);
 int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems, const int32_t *winner,
                        const int32_t *pixel, int64_t n, int32_t C, float *gcell /*[n,C] zeroed scratch*/,
