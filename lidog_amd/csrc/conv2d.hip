@@ -3,8 +3,8 @@
 // Reference: Encoder2D = Conv2d(k3,s2,p1,bias=False) x2 + Conv2d(k1) (utils/models/conv2d.py:16-22,
 // 116,184-185), NCHW float32.  CPU checker: oracle/ref_torch.py:Encoder2DRef (torch CPU conv).
 //
-// One kernel template computes D[i][j] = sum_k A(i,k) * B(k,j) on 128x128 tiles, 16-deep LDS stages,
-// 4 waves x (2x2) MFMA 32x32 tiles.  j always runs over pixels so that the D columns (MFMA lane
+// Every kernel computes D[i][j] = sum_k A(i,k) * B(k,j) on 128x128 (or 96x128) tiles, 32-deep LDS stages,
+// 4 waves x MFMA 32x32 tiles.  j always runs over pixels so that the D columns (MFMA lane
 // dimension) are contiguous in NCHW memory:
 //   FWD    i = co, k = (ci,ky,kx), j = (b,yo,xo)   A = W[co][k]            B = im2col(X)
 //   DGRAD  i = ci, k = (co,tap),   j = class pixel  A = Wd[class][ci][k]   B = gathered gY   (4 stride-2
@@ -15,7 +15,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define IG_T 128
-#define IG_KB 16
 #define IG_LD 132
 
 struct IgParams {
@@ -33,135 +32,88 @@ struct IgParams {
 
 enum { IG_FWD = 0, IG_DGRAD = 1, IG_WGRAD = 2 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_igemm(IgParams p) {
-    __shared__ float As[IG_KB * IG_LD];
-    __shared__ float Bs[IG_KB * IG_LD];
+// ------------------------------------------------------------------ WGRAD
+// D[co][(ci,ky,kx)] = sum over pixels k = (b,yo,xo) of gY[co][k] * X[ci][2yo-1+ky][2xo-1+kx], split over k.
+// 128 x 128 tile, 32 pixels per stage.  Thread (kk = tid & 31, rg = tid >> 5) stages pixel kk of 16 gY rows
+// and 16 im2col columns; its (ci,ky,kx) columns are fixed for the whole kernel (packed offset + tap), its pixel
+// advances by 32 per stage with adds only.  Loads are unconditional (invalid taps read element 0) and zeroed
+// when the stage is written to LDS; LDS row pitch 129 makes the transposing stores conflict-free.
+#define WG_KB 32
+#define WG_LD 129
+__global__ __launch_bounds__(256) void k_conv_wgrad(IgParams p) {
+    __shared__ float As[WG_KB * WG_LD];
+    __shared__ float Bs[WG_KB * WG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.y * IG_T, j0 = blockIdx.x * IG_T;
-    const int HoWo = p.Ho * p.Wo;
-    int k_begin = 0, k_end = p.Kd;
-    if (MODE == IG_WGRAD) {
-        k_begin = blockIdx.z * p.k_chunk;
-        k_end = k_begin + p.k_chunk < p.Kd ? k_begin + p.k_chunk : p.Kd;
+    const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+    const int k_begin = blockIdx.z * p.k_chunk;
+    const int k_end = k_begin + p.k_chunk < p.Kd ? k_begin + p.k_chunk : p.Kd;
+    const int kk = tid & 31, rg = tid >> 5;
+
+    int cpk[16];  // ((element offset of the tap relative to the window corner) << 4) | tap, -1 past Nj
+    unsigned a_mask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int j = j0 + rg + 8 * r;
+        cpk[r] = -1;
+        if (j < p.Nj) {
+            int ci = j / 9, t = j - ci * 9;
+            int ty = t / 3, tx = t - ty * 3;
+            cpk[r] = ((ci * HW + ty * p.W + tx) << 4) | t;
+        }
+        a_mask |= (unsigned)(i0 + rg + 8 * r < p.Mi) << r;
+    }
+    // pixel of this thread in the current stage (clamped to the last pixel once past the end)
+    int m = k_begin + kk;
+    int pb, yo, xo;
+    {
+        int mc = m < p.Kd ? m : p.Kd - 1;
+        pb = mc / HoWo;
+        int r_ = mc - pb * HoWo;
+        yo = r_ / p.Wo;
+        xo = r_ - yo * p.Wo;
     }
 
-    // ---- per-thread invariant decode
-    // FWD/DGRAD: B element (kk = tid/128 + 2r, jj = tid%128): the pixel is fixed per thread
-    int pb = 0, pyy = 0, pxx = 0;
-    bool jvalid = false;
-    if (MODE != IG_WGRAD) {
-        int j = j0 + (tid & 127);
-        jvalid = j < p.Nj;
-        int jj = jvalid ? j : 0;
-        if (MODE == IG_FWD) {
-            pb = jj / HoWo;
-            int r = jj - pb * HoWo;
-            pyy = r / p.Wo;
-            pxx = r - pyy * p.Wo;
-        } else {
-            int hw = p.Hc * p.Wc;
-            pb = jj / hw;
-            int r = jj - pb * hw;
-            pyy = (r / p.Wc) * 2 + p.py;  // input-image pixel of this class
-            pxx = (r % p.Wc) * 2 + p.px;
+    float ra[16], rb[16];
+    unsigned okb = 0;
+    bool mv = false;
+    auto load_stage = [&]() {
+        mv = m < k_end;
+        const int a_base = (pb * p.Cout + i0 + rg) * HoWo + yo * p.Wo + xo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ra[r] = p.A[a_base + (((a_mask >> r) & 1u) ? r * 8 * HoWo : 0)];
+        const int b_base = pb * p.Cin * HW + (2 * yo - 1) * p.W + 2 * xo - 1;  // window corner (may lie outside)
+        const unsigned ym = (unsigned)(yo > 0) | 2u | ((unsigned)(2 * yo + 1 < p.H) << 2);
+        const unsigned xm = (unsigned)(xo > 0) | 2u | ((unsigned)(2 * xo + 1 < p.W) << 2);
+        const unsigned tapmask = mv ? (((ym & 1u) ? xm : 0u) | ((ym & 2u) ? xm << 3 : 0u) | ((ym & 4u) ? xm << 6 : 0u)) : 0u;
+        okb = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = cpk[r];
+            const unsigned ok = (c >= 0) ? ((tapmask >> (c & 15)) & 1u) : 0u;
+            okb |= ok << r;
+            rb[r] = p.Bm[ok ? b_base + (c >> 4) : 0];
         }
-    }
-    // WGRAD: B element (kk = tid%16, jj = tid/16 + 16r): the 8 (ci,ky,kx) columns are fixed per thread
-    int w_off[8];
-    int w_dy[8], w_dx[8];
-    if (MODE == IG_WGRAD) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            int j = j0 + (tid >> 4) + 16 * r;
-            if (j < p.Nj) {
-                int ci = j / 9, t = j - ci * 9;
-                w_dy[r] = t / 3 - 1;
-                w_dx[r] = t % 3 - 1;
-                w_off[r] = ci * p.H * p.W;
-            } else {
-                w_off[r] = -1; w_dy[r] = 0; w_dx[r] = 0;
+    };
+    auto advance = [&]() {
+        m += WG_KB;
+        if (m < p.Kd) {
+            xo += WG_KB;
+            while (xo >= p.Wo) {
+                xo -= p.Wo;
+                ++yo;
             }
-        }
-    }
-
-    float ra[8], rb[8];
-    auto load_stage = [&](int k0) {
-        // ---- A
-        if (MODE == IG_WGRAD) {
-            int m = k0 + (tid & 15);
-            bool mv = m < k_end;
-            int b = mv ? m / HoWo : 0;
-            int r_ = mv ? m - b * HoWo : 0;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                int i = i0 + (tid >> 4) + 16 * r;
-                ra[r] = (mv && i < p.Mi) ? p.A[((size_t)b * p.Cout + i) * HoWo + r_] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                int f = tid + 256 * v;
-                int i = i0 + (f >> 2), q = f & 3;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < p.Mi) t = *reinterpret_cast<const float4 *>(p.A + (size_t)i * p.Kd + k0 + q * 4);
-                ra[4 * v] = t.x; ra[4 * v + 1] = t.y; ra[4 * v + 2] = t.z; ra[4 * v + 3] = t.w;
-            }
-        }
-        // ---- B
-        if (MODE == IG_FWD) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                int kk = k0 + (tid >> 7) + 2 * r;
-                int ci = kk / 9, t = kk - ci * 9;
-                int y = pyy * 2 - 1 + t / 3, x = pxx * 2 - 1 + t % 3;
-                bool ok = jvalid && y >= 0 && y < p.H && x >= 0 && x < p.W;
-                rb[r] = ok ? p.Bm[(((size_t)pb * p.Cin + ci) * p.H + y) * p.W + x] : 0.f;
-            }
-        } else if (MODE == IG_DGRAD) {
-            const int nt = p.nky * p.nkx;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                int kk = k0 + (tid >> 7) + 2 * r;
-                int co = kk / nt, tap = kk - co * nt;
-                int ky = p.ky0 + (tap / p.nkx) * p.kystep, kx = p.kx0 + (tap % p.nkx) * p.kxstep;
-                int yo2 = pyy + 1 - ky, xo2 = pxx + 1 - kx;  // even by construction of the class
-                int yo = yo2 >> 1, xo = xo2 >> 1;
-                bool ok = jvalid && yo2 >= 0 && xo2 >= 0 && yo < p.Ho && xo < p.Wo;
-                rb[r] = ok ? p.Bm[(((size_t)pb * p.Cout + co) * p.Ho + yo) * p.Wo + xo] : 0.f;
-            }
-        } else {
-            int m = k0 + (tid & 15);
-            bool mv = m < k_end;
-            int b = mv ? m / HoWo : 0;
-            int r_ = mv ? m - b * HoWo : 0;
-            int yo = r_ / p.Wo, xo = r_ - yo * p.Wo;
-            size_t base = (size_t)b * p.Cin * p.H * p.W;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                int y = yo * 2 + w_dy[r], x = xo * 2 + w_dx[r];
-                bool ok = mv && w_off[r] >= 0 && y >= 0 && y < p.H && x >= 0 && x < p.W;
-                rb[r] = ok ? p.Bm[base + w_off[r] + (size_t)y * p.W + x] : 0.f;
+            while (yo >= p.Ho) {
+                yo -= p.Ho;
+                ++pb;
             }
         }
     };
     auto store_stage = [&]() {
-        if (MODE == IG_WGRAD) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                As[(tid & 15) * IG_LD + (tid >> 4) + 16 * r] = ra[r];
-                Bs[(tid & 15) * IG_LD + (tid >> 4) + 16 * r] = rb[r];
-            }
-        } else {
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                int f = tid + 256 * v;
-                int il = f >> 2, q = f & 3;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) As[(q * 4 + s) * IG_LD + il] = ra[4 * v + s];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) Bs[((tid >> 7) + 2 * r) * IG_LD + (tid & 127)] = rb[r];
+        for (int r = 0; r < 16; ++r) {
+            As[kk * WG_LD + rg + 8 * r] = (mv && ((a_mask >> r) & 1u)) ? ra[r] : 0.f;
+            Bs[kk * WG_LD + rg + 8 * r] = ((okb >> r) & 1u) ? rb[r] : 0.f;
         }
     };
 
@@ -172,162 +124,187 @@ __global__ __launch_bounds__(256) void k_igemm(IgParams p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
     const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
     const int li = lane & 31, kh = lane >> 5;
+    const float *a_rd = &As[kh * WG_LD + wi + li];
+    const float *b_rd = &Bs[kh * WG_LD + wj + li];
 
-    if (k_begin < k_end) load_stage(k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += IG_KB) {
+    load_stage();
+    for (int k0 = k_begin; k0 < k_end; k0 += WG_KB) {
         __syncthreads();
         store_stage();
         __syncthreads();
-        if (k0 + IG_KB < k_end) load_stage(k0 + IG_KB);
+        advance();
+        load_stage();  // unconditional prefetch: past the end it re-reads the last pixel and is zeroed (mv false)
+        float af[2], bf[2], an[2], bn[2];
+        af[0] = a_rd[0]; af[1] = a_rd[32];
+        bf[0] = b_rd[0]; bf[1] = b_rd[32];
 #pragma unroll
-        for (int k2 = 0; k2 < IG_KB / 2; ++k2) {
-            float a0 = As[(2 * k2 + kh) * IG_LD + wi + li];
-            float a1 = As[(2 * k2 + kh) * IG_LD + wi + 32 + li];
-            float b0 = Bs[(2 * k2 + kh) * IG_LD + wj + li];
-            float b1 = Bs[(2 * k2 + kh) * IG_LD + wj + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int k2 = 0; k2 < WG_KB / 2; ++k2) {
+            if (k2 + 1 < WG_KB / 2) {
+                an[0] = a_rd[(2 * k2 + 2) * WG_LD]; an[1] = a_rd[(2 * k2 + 2) * WG_LD + 32];
+                bn[0] = b_rd[(2 * k2 + 2) * WG_LD]; bn[1] = b_rd[(2 * k2 + 2) * WG_LD + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k2 + 1 < WG_KB / 2) {
+                af[0] = an[0]; af[1] = an[1];
+                bf[0] = bn[0]; bf[1] = bn[1];
+            }
         }
     }
 
-    // ---- epilogue.  D layout of 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    // D layout of 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         int j = j0 + wj + 32 * tj + li;
         if (j >= p.Nj) continue;
-        size_t col_off;
-        size_t i_stride;
-        if (MODE == IG_FWD) {
-            int b = j / HoWo;
-            col_off = (size_t)b * p.Cout * HoWo + (j - b * HoWo);
-            i_stride = HoWo;
-        } else if (MODE == IG_DGRAD) {
-            int hw = p.Hc * p.Wc;
-            int b = j / hw;
-            int r = j - b * hw;
-            int y = (r / p.Wc) * 2 + p.py, x = (r % p.Wc) * 2 + p.px;
-            col_off = (size_t)b * p.Cin * p.H * p.W + (size_t)y * p.W + x;
-            i_stride = (size_t)p.H * p.W;
-        } else {
-            col_off = (size_t)blockIdx.z * p.Mi * p.Nj + j;
-            i_stride = p.Nj;
-        }
+        float *d = p.D + (size_t)blockIdx.z * p.Mi * p.Nj + j;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int i = i0 + wi + 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (i < p.Mi) p.D[col_off + (size_t)i * i_stride] = acc[ti][tj][e];
+                if (i < p.Mi) d[(size_t)i * p.Nj] = acc[ti][tj][e];
             }
         }
     }
 }
 
-// ------------------------------------------------------------------ FWD / DGRAD, second generation
-// Same tiling as k_igemm, but 32-deep stages and all reduction-index arithmetic on the scalar unit: the
-// reduction row kk of a staged B element is wave-uniform (kw + 2r), so (ci,ky,kx) / (co,tap) and the address
-// offset they imply are SGPR values; per lane only a validity bit (precomputed 3-bit row/column masks), one
-// add and two selects remain.  Invalid taps load a known-good address and are zeroed by select (no branch
-// around a load).
+// ------------------------------------------------------------------ FWD / DGRAD, table-driven
+// Same 128-pixel-wide tiles as k_igemm with 32-deep stages, built so that a stage costs ~150 instructions per
+// wave besides its MFMAs (the first version spent ~530 on reduction-index arithmetic, as long as the MFMA phase):
+//  - the reduction index kk -> (address offset, tap) map is computed once per workgroup into an LDS table;
+//    per staged element only a table read, a tap-validity bit test (per-lane 9-bit / 4-bit mask), one add
+//    and one select remain; all offsets are 32-bit;
+//  - invalid taps load a known-good address; they (and rows past Mi) are zeroed when the stage is written to
+//    LDS, not after the load: a select right behind a load makes the wave wait for it before its MFMA phase;
+//  - the LDS operand reads of MFMA step k2+1 are issued before the MFMAs of step k2 (sched_barrier).
+// WM x (4/WM) waves, each TI x TJ MFMA tiles: 128 x 128 (WM=2,TI=2,TJ=2) or 96 x 128 (WM=1,TI=3,TJ=1; the
+// data gradient of a 96-channel input would waste a quarter of a 128-row tile).
 #define C2_KB 32
-template <int MODE>
+template <int MODE, int WM, int TI, int TJ>
 __global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
+    constexpr int TMR = WM * TI * 32;              // tile rows (i)
+    constexpr int AV = (TMR * C2_KB / 4) / 256;    // float4 of A per thread per stage
+    static_assert((4 / WM) * TJ * 32 == IG_T, "tile is 128 pixels wide");
+    static_assert((TMR * C2_KB / 4) % 256 == 0, "A stage must divide over the threads");
     __shared__ float As[C2_KB * IG_LD];
     __shared__ float Bs[C2_KB * IG_LD];
+    extern __shared__ int2 s_tab[];  // [Kd] (offset, tap)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.y * IG_T, j0 = blockIdx.x * IG_T;
+    const int i0 = blockIdx.y * TMR, j0 = blockIdx.x * IG_T;
     const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
     const int kw = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int nt = p.nky * p.nkx;
 
-    // ---- the pixel of this lane (fixed for the whole kernel)
+    for (int kk = tid; kk < p.Kd; kk += 256) {
+        int koff, t;
+        if (MODE == IG_FWD) {
+            int ci = kk / 9;
+            t = kk - ci * 9;
+            int ty = t / 3, tx = t - ty * 3;
+            koff = ci * HW + (ty - 1) * p.W + (tx - 1);
+        } else {
+            int co = kk / nt, tap = kk - co * nt;
+            int ty = tap / p.nkx, tx = tap - ty * p.nkx;
+            koff = co * HoWo - ty * p.Wo - tx;
+            t = ty * 2 + tx;
+        }
+        s_tab[kk] = make_int2(koff, t);
+    }
+
+    // ---- the pixel of this lane (fixed for the whole kernel): 32-bit element offsets, tap validity mask
     const int j = j0 + (tid & 127);
     const bool jvalid = j < p.Nj;
     const int jj = jvalid ? j : 0;
-    size_t base, safe;
-    unsigned ymask = 0, xmask = 0;
+    int base, safe;
+    unsigned tapmask = 0;
     if (MODE == IG_FWD) {
         int pb = jj / HoWo, r = jj - pb * HoWo;
         int yo = r / p.Wo, xo = r - yo * p.Wo;
-        base = (size_t)pb * p.Cin * HW + (size_t)(2 * yo) * p.W + 2 * xo;  // centre tap, always inside the image
+        base = pb * p.Cin * HW + (2 * yo) * p.W + 2 * xo;  // centre tap, always inside the image
         safe = base;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            int y = 2 * yo - 1 + t, x = 2 * xo - 1 + t;
-            ymask |= (unsigned)(y >= 0 && y < p.H) << t;
-            xmask |= (unsigned)(x >= 0 && x < p.W) << t;
-        }
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                int y = 2 * yo - 1 + ty, x = 2 * xo - 1 + tx;
+                tapmask |= (unsigned)(y >= 0 && y < p.H && x >= 0 && x < p.W) << (ty * 3 + tx);
+            }
     } else {
         int hw = p.Hc * p.Wc;
         int pb = jj / hw, r = jj - pb * hw;
         int pyy = (r / p.Wc) * 2 + p.py, pxx = (r % p.Wc) * 2 + p.px;
         int y0 = (pyy + 1 - p.ky0) >> 1, x0 = (pxx + 1 - p.kx0) >> 1;  // output pixel of the class's first tap
-        safe = (size_t)pb * p.Cout * HoWo;
-        base = safe + (size_t)y0 * p.Wo + x0;   // y0 - t / x0 - t for the later taps
+        safe = pb * p.Cout * HoWo;
+        base = safe + y0 * p.Wo + x0;  // y0 - ty / x0 - tx for the later taps
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            ymask |= (unsigned)(y0 - t >= 0 && y0 - t < p.Ho) << t;
-            xmask |= (unsigned)(x0 - t >= 0 && x0 - t < p.Wo) << t;
-        }
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+                tapmask |= (unsigned)(y0 - ty >= 0 && y0 - ty < p.Ho && x0 - tx >= 0 && x0 - tx < p.Wo)
+                           << (ty * 2 + tx);
     }
-    if (!jvalid) ymask = 0;
-    const int nt = p.nky * p.nkx;
+    if (!jvalid) tapmask = 0;
 
-    float ra[16], rb[16];
+    // ---- the A rows this thread stages
+    const float *a_ptr[AV];
+    bool a_ok[AV];
+#pragma unroll
+    for (int v = 0; v < AV; ++v) {
+        int f = tid + 256 * v;
+        int i = i0 + (f >> 3);
+        a_ok[v] = i < p.Mi;
+        a_ptr[v] = p.A + (size_t)(a_ok[v] ? i : p.Mi - 1) * p.Kd + (f & 7) * 4;
+    }
+    __syncthreads();  // table complete
+
+    float4 ra[AV];
+    float rb[16];
+    unsigned okbits = 0;
     auto load_stage = [&](int k0) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            int f = tid + 256 * v;
-            int i = i0 + (f >> 3), q = f & 7;
-            bool iok = i < p.Mi;
-            float4 t = *reinterpret_cast<const float4 *>(p.A + (size_t)(iok ? i : p.Mi - 1) * p.Kd + k0 + q * 4);
-            ra[4 * v] = iok ? t.x : 0.f; ra[4 * v + 1] = iok ? t.y : 0.f;
-            ra[4 * v + 2] = iok ? t.z : 0.f; ra[4 * v + 3] = iok ? t.w : 0.f;
-        }
+        for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const float4 *>(a_ptr[v] + k0);
+        okbits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kk = k0 + kw + 2 * r;  // wave-uniform
-            int koff, ty, tx;
-            if (MODE == IG_FWD) {
-                int ci = kk / 9, t = kk - ci * 9;
-                ty = t / 3; tx = t - ty * 3;
-                koff = ci * HW + (ty - 1) * p.W + (tx - 1);
-            } else {
-                int co = kk / nt, tap = kk - co * nt;
-                ty = tap / p.nkx; tx = tap - ty * p.nkx;
-                koff = co * HoWo - ty * p.Wo - tx;
-            }
-            bool ok = ((ymask >> ty) & (xmask >> tx) & 1u) != 0;
-            size_t addr = ok ? (size_t)((long long)base + koff) : safe;
-            float v = p.Bm[addr];
-            rb[r] = ok ? v : 0.f;
+            const int2 e = s_tab[k0 + kw + 2 * r];  // wave-uniform address: a broadcast read
+            const unsigned ok = (tapmask >> e.y) & 1u;
+            okbits |= ok << r;
+            rb[r] = p.Bm[ok ? base + e.x : safe];
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
+        for (int v = 0; v < AV; ++v) {
             int f = tid + 256 * v;
             int il = f >> 3, q = f & 7;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) As[(q * 4 + e) * IG_LD + il] = ra[4 * v + e];
+            const bool ok = a_ok[v];
+            As[(q * 4 + 0) * IG_LD + il] = ok ? ra[v].x : 0.f;
+            As[(q * 4 + 1) * IG_LD + il] = ok ? ra[v].y : 0.f;
+            As[(q * 4 + 2) * IG_LD + il] = ok ? ra[v].z : 0.f;
+            As[(q * 4 + 3) * IG_LD + il] = ok ? ra[v].w : 0.f;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Bs[(kw + 2 * r) * IG_LD + (tid & 127)] = rb[r];
+        for (int r = 0; r < 16; ++r) Bs[(kw + 2 * r) * IG_LD + (tid & 127)] = ((okbits >> r) & 1u) ? rb[r] : 0.f;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TJ; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+    const int wi = (WM == 1 ? 0 : (wave >> 1)) * (TI * 32), wj = (WM == 1 ? wave : (wave & 1)) * (TJ * 32);
     const int li = lane & 31, kh = lane >> 5;
+    const float *a_rd = &As[kh * IG_LD + wi + li];
+    const float *b_rd = &Bs[kh * IG_LD + wj + li];
 
     load_stage(0);
     for (int k0 = 0; k0 < p.Kd; k0 += C2_KB) {
@@ -335,21 +312,37 @@ __global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
         store_stage();
         __syncthreads();
         load_stage(k0 + C2_KB < p.Kd ? k0 + C2_KB : k0);  // unconditional prefetch (last stage re-reads itself)
+        float af[TI], bf[TJ], an[TI], bn[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a) af[a] = a_rd[32 * a];
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) bf[b] = b_rd[32 * b];
 #pragma unroll
         for (int k2 = 0; k2 < C2_KB / 2; ++k2) {
-            float a0 = As[(2 * k2 + kh) * IG_LD + wi + li];
-            float a1 = As[(2 * k2 + kh) * IG_LD + wi + 32 + li];
-            float b0 = Bs[(2 * k2 + kh) * IG_LD + wj + li];
-            float b1 = Bs[(2 * k2 + kh) * IG_LD + wj + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (k2 + 1 < C2_KB / 2) {
+#pragma unroll
+                for (int a = 0; a < TI; ++a) an[a] = a_rd[(2 * k2 + 2) * IG_LD + 32 * a];
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) bn[b] = b_rd[(2 * k2 + 2) * IG_LD + 32 * b];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < TJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k2 + 1 < C2_KB / 2) {
+#pragma unroll
+                for (int a = 0; a < TI; ++a) af[a] = an[a];
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) bf[b] = bn[b];
+            }
         }
     }
 
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
+    for (int tj = 0; tj < TJ; ++tj) {
         int jo = j0 + wj + 32 * tj + li;
         if (jo >= p.Nj) continue;
         size_t col_off, i_stride;
@@ -365,7 +358,7 @@ __global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
             i_stride = HW;
         }
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+        for (int ti = 0; ti < TI; ++ti) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 int i = i0 + wi + 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -500,8 +493,10 @@ extern "C" int lidog_conv2d_fwd(const float *x, const float *w, const float *bia
     p.Ho = out_dim(H, 3, 2, 1); p.Wo = out_dim(W, 3, 2, 1);
     p.Mi = Cout; p.Nj = B * p.Ho * p.Wo; p.Kd = Cin * 9;
     if (p.Nj == 0) return 0;
+    LIDOG_REQUIRE((int64_t)B * Cin * H * W < ((int64_t)1 << 31) && (int64_t)p.Kd * 8 <= 24576,
+                  "conv2d_fwd: tensor too large for 32-bit offsets / reduction table");
     dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
-    k_conv_s2<IG_FWD><<<grid, 256, 0, st>>>(p);
+    k_conv_s2<IG_FWD, 2, 2, 2><<<grid, 256, (size_t)p.Kd * sizeof(int2), st>>>(p);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -520,6 +515,9 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
     LIDOG_REQUIRE(ksize == 3 && stride == 2 && pad == 1, "conv2d_dgrad: MFMA path implements k3 s2 p1");
     LIDOG_REQUIRE(ws != nullptr, "conv2d_dgrad: needs a 9*Cin*Cout float workspace for the repacked weights");
     LIDOG_REQUIRE(Cout % C2_KB == 0, "conv2d_dgrad: Cout must be a multiple of 32");
+    LIDOG_REQUIRE((int64_t)B * Cout * out_dim(H, 3, 2, 1) * out_dim(W, 3, 2, 1) < ((int64_t)1 << 31) &&
+                      (int64_t)Cout * 4 * 8 <= 24576,
+                  "conv2d_dgrad: tensor too large for 32-bit offsets / reduction table");
     int Ho = out_dim(H, 3, 2, 1), Wo = out_dim(W, 3, 2, 1);
     float *slab = ws;
     for (int py = 0; py < 2; ++py) {
@@ -540,8 +538,14 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
             p.A = slab;
             slab += total;
             if (p.Nj > 0) {
-                dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
-                k_conv_s2<IG_DGRAD><<<grid, 256, 0, st>>>(p);
+                const size_t tab = (size_t)p.Kd * sizeof(int2);
+                if (Cin % 128 != 0 && Cin % 96 == 0) {  // 96-row tiles: no idle quarter of a 128-row tile
+                    dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)(p.Mi / 96), 1);
+                    k_conv_s2<IG_DGRAD, 1, 3, 1><<<grid, 256, tab, st>>>(p);
+                } else {
+                    dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
+                    k_conv_s2<IG_DGRAD, 2, 2, 2><<<grid, 256, tab, st>>>(p);
+                }
             }
         }
     }
@@ -568,15 +572,19 @@ extern "C" int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, in
     int64_t slab = (int64_t)p.Mi * p.Nj;
     int tiles = (int)(cdiv64(p.Nj, IG_T) * cdiv64(p.Mi, IG_T));
     int splits = (int)cdiv64(1024, tiles);
-    int64_t max_by_k = cdiv64(p.Kd, 4 * IG_KB);
+    LIDOG_REQUIRE(Cout % 8 == 0, "conv2d_wgrad: Cout must be a multiple of 8");
+    LIDOG_REQUIRE((int64_t)Cin * H * W < ((int64_t)1 << 27) && (int64_t)B * Cin * H * W < ((int64_t)1 << 31) &&
+                      (int64_t)B * Cout * p.Ho * p.Wo < ((int64_t)1 << 31),
+                  "conv2d_wgrad: tensor too large for the packed 32-bit offsets");
+    int64_t max_by_k = cdiv64(p.Kd, 4 * WG_KB);
     if (splits > max_by_k) splits = (int)(max_by_k < 1 ? 1 : max_by_k);
     if ((int64_t)splits * slab > ws_floats) splits = (int)(ws_floats / slab);
     LIDOG_REQUIRE(splits >= 1, "conv2d_wgrad: workspace too small (%lld floats needed per split)", (long long)slab);
-    p.k_chunk = (int)(cdiv64(cdiv64(p.Kd, splits), IG_KB) * IG_KB);
+    p.k_chunk = (int)(cdiv64(cdiv64(p.Kd, splits), WG_KB) * WG_KB);
     splits = (int)cdiv64(p.Kd, p.k_chunk);
     p.D = (splits == 1) ? gw : ws;
     dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), (unsigned)splits);
-    k_igemm<IG_WGRAD><<<grid, 256, 0, st>>>(p);
+    k_conv_wgrad<<<grid, 256, 0, st>>>(p);
     if (splits > 1) k_sum_splits<<<(unsigned)cdiv64(slab, 256), 256, 0, st>>>(ws, slab, splits, gw);
     LIDOG_LAUNCH_CHECK();
     return 0;

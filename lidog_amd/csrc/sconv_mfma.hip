@@ -15,6 +15,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MG_BK 32
 #define MG_SA 33  // odd row stride: the 32 lanes of an A read (one row each) hit 32 different banks
 
+template <int NT>
+__device__ __forceinline__ void frag_load(const float *p, float (&f)[NT]) {
+    if constexpr (NT == 4) {
+        float4 v = *reinterpret_cast<const float4 *>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else if constexpr (NT == 2) {
+        float2 v = *reinterpret_cast<const float2 *>(p);
+        f[0] = v.x; f[1] = v.y;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f[t] = p[t];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
+    if constexpr (NT == 4) {
+        *reinterpret_cast<float4 *>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    } else if constexpr (NT == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(f[0], f[1]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) p[t] = f[t];
+    }
+}
+
 // ------------------------------------------------------------------ gathered GEMM
 // Tile 128 pair-rows x 32*NT columns; wave w owns rows [32w, 32w+32) and all NT column tiles.
 template <int NT>
@@ -64,16 +90,23 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
     }
 #define MG_STOREB(J, R) \
     if constexpr (BV > J) *reinterpret_cast<float4 *>(&Bs[(tid + 256 * J) * 4]) = R;
+    // the 4 gathered rows this thread stages (8 lanes fetch one 128-B line of a row), fixed for the tile
+    const float *a_row[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int f = tid + 256 * j;
+        int src = s_src[f >> 3];
+        a_ok[j] = src >= 0;
+        a_row[j] = A + (size_t)(src < 0 ? 0 : src) * Cin + (f & 7) * 4;
+    }
     auto load_chunk = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int f = tid + 256 * j;
-            int r = f >> 3, q = f & 7;  // 8 lanes fetch one 128-B line of a gathered row
-            int src = s_src[r];
-            // unconditional load + select (a branch around the load would serialise the gather)
-            float4 v = *reinterpret_cast<const float4 *>(A + (size_t)(src < 0 ? 0 : src) * Cin + kb + q * 4);
-            bool ok = src >= 0;
-            ra[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            // unconditional load (a branch around the load would serialise the gather); rows past the end of
+            // the tile are zeroed when the chunk is written to LDS -- a select here would make the wave wait
+            // for the gather before its MFMA phase instead of after it
+            ra[j] = *reinterpret_cast<const float4 *>(a_row[j] + kb);
         }
         MG_LOADB(0, rb0) MG_LOADB(1, rb1) MG_LOADB(2, rb2) MG_LOADB(3, rb3)
     };
@@ -83,10 +116,11 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
             int f = tid + 256 * j;
             int r = f >> 3, q = f & 7;
             const int o = r * MG_SA + q * 4;
-            As[o] = ra[j].x;
-            As[o + 1] = ra[j].y;
-            As[o + 2] = ra[j].z;
-            As[o + 3] = ra[j].w;
+            const bool ok = a_ok[j];
+            As[o] = ok ? ra[j].x : 0.f;
+            As[o + 1] = ok ? ra[j].y : 0.f;
+            As[o + 2] = ok ? ra[j].z : 0.f;
+            As[o + 3] = ok ? ra[j].w : 0.f;
         }
         MG_STOREB(0, rb0) MG_STOREB(1, rb1) MG_STOREB(2, rb2) MG_STOREB(3, rb3)
     };
@@ -106,28 +140,60 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
         // registers sends them through scratch memory
         load_chunk(kb + MG_BK < Cin ? kb + MG_BK : kb);
         const float *arow = &As[(wave * 32 + li) * MG_SA + kh];
-        const float *bcol = &Bs[kh * TN + li];
+        // MFMA column tile t of this wave = columns {li * NT + t}: the NT B operands of one k step are adjacent
+        // in the row-major LDS image (one wide LDS read), and the NT results of a lane are adjacent in T (one
+        // wide store).  The operands of step k2+1 are requested before the MFMAs of step k2 are issued.
+        const float *bcol = &Bs[kh * TN + li * NT];
+        // two k steps per round; sched_barrier pins the order "request round j+1, then multiply round j"
+        // (left alone, the scheduler sinks the LDS reads below the MFMAs and every round waits a full LDS
+        // latency with the matrix pipe idle)
+        float bq0[NT], bq1[NT], bn0[NT], bn1[NT], a0, a1, an0, an1;
+        frag_load<NT>(bcol, bq0);
+        frag_load<NT>(bcol + 2 * TN, bq1);
+        a0 = arow[0];
+        a1 = arow[2];
 #pragma unroll
-        for (int k2 = 0; k2 < MG_BK / 2; ++k2) {
-            float a = arow[2 * k2];
+        for (int j = 0; j < MG_BK / 4; ++j) {
+            if (j + 1 < MG_BK / 4) {
+                frag_load<NT>(bcol + (4 * j + 4) * TN, bn0);
+                frag_load<NT>(bcol + (4 * j + 6) * TN, bn1);
+                an0 = arow[4 * j + 4];
+                an1 = arow[4 * j + 6];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcol[2 * k2 * TN + 32 * t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 1 < MG_BK / 4) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bq0[t] = bn0[t];
+                    bq1[t] = bn1[t];
+                }
+                a0 = an0;
+                a1 = an1;
+            }
         }
     }
 
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[col0 + li * NT + t] : 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         int dst = s_dst[r];
         if (dst >= 0) {
-            float *out = T + (size_t)dst * Cout + col0 + li;
+            float *out = T + (size_t)dst * Cout + col0 + li * NT;
+            float v[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                float v = acc[t][e];
-                if (bias) v += bias[col0 + 32 * t + li];
-                out[32 * t] = v;
+                v[t] = acc[t][e];
+                if (bias) v[t] += bv[t];
             }
+            frag_store<NT>(out, v);
         }
     }
 }
@@ -223,18 +289,16 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
             int f = tid + NTH * j;
             f = f < MW_R * TM / 4 ? f : MW_R * TM / 4 - 1;
             int r = f / (TM / 4), c4 = f % (TM / 4);
-            float4 v = *reinterpret_cast<const float4 *>(A + (size_t)ia[j] * Cin + ci0 + c4 * 4);
-            bool ok = p + r < p1;
-            ra[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            (void)r;
+            ra[j] = *reinterpret_cast<const float4 *>(A + (size_t)ia[j] * Cin + ci0 + c4 * 4);
         }
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
             int f = tid + NTH * j;
             f = f < MW_R * TN / 4 ? f : MW_R * TN / 4 - 1;
             int r = f / (TN / 4), c4 = f % (TN / 4);
-            float4 v = *reinterpret_cast<const float4 *>(G + (size_t)ig[j] * Cout + co0 + c4 * 4);
-            bool ok = p + r < p1;
-            rg[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            (void)r;
+            rg[j] = *reinterpret_cast<const float4 *>(G + (size_t)ig[j] * Cout + co0 + c4 * 4);
         }
     };
     if (p0 < p1) {
@@ -247,27 +311,57 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
 #pragma unroll
         for (int j = 0; j < AV; ++j) {
             int f = tid + NTH * j;
-            if (f < MW_R * TM / 4) *reinterpret_cast<float4 *>(&As[f * 4]) = ra[j];
+            // pair rows past the end of the item are zeroed here, not at load time: a select right after the
+            // load would make the wave wait for the gather before its MFMA phase instead of after it
+            // (componentwise selects: a ternary on a whole float4 goes through scratch memory)
+            const bool ok = p + f / (TM / 4) < p1;
+            if (f < MW_R * TM / 4) *reinterpret_cast<float4 *>(&As[f * 4]) = make_float4(ok ? ra[j].x : 0.f, ok ? ra[j].y : 0.f, ok ? ra[j].z : 0.f, ok ? ra[j].w : 0.f);
         }
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
             int f = tid + NTH * j;
-            if (f < MW_R * TN / 4) *reinterpret_cast<float4 *>(&Gs[f * 4]) = rg[j];
+            const bool ok = p + f / (TN / 4) < p1;
+            if (f < MW_R * TN / 4) *reinterpret_cast<float4 *>(&Gs[f * 4]) = make_float4(ok ? rg[j].x : 0.f, ok ? rg[j].y : 0.f, ok ? rg[j].z : 0.f, ok ? rg[j].w : 0.f);
         }
         __syncthreads();
         if (p + MW_R < p1) {
             load_rows(p + MW_R);
             load_idx(p + 2 * MW_R);
         }
-        // compile-time trip count (the group only offsets the address) so the LDS reads of all steps can be
-        // issued ahead of the MFMA chain with counted lgkmcnt waits
+        // compile-time trip count (the group only offsets the address); the operands of step q+1 are requested
+        // before the MFMAs of step q are issued (sched_barrier pins that order: left alone, the scheduler sinks
+        // the LDS reads below the MFMAs and every step waits an LDS latency with the matrix pipe idle)
+        constexpr int Q = MW_R / 2 / NGRP;
+        float af[TPW], gf[TPW], an[TPW], gn[TPW];
+        {
+            const int kk = 2 * grp + kh;
 #pragma unroll
-        for (int q = 0; q < MW_R / 2 / NGRP; ++q) {
-            const int kk = 2 * (q * NGRP + grp) + kh;
+            for (int t = 0; t < TPW; ++t) {
+                af[t] = As[kk * TM + a_off[t]];
+                gf[t] = Gs[kk * TN + g_off[t]];
+            }
+        }
 #pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk * TM + a_off[t]], Gs[kk * TN + g_off[t]], acc[t],
-                                                              0, 0, 0);
+        for (int q = 0; q < Q; ++q) {
+            if (q + 1 < Q) {
+                const int kk = 2 * ((q + 1) * NGRP + grp) + kh;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    an[t] = As[kk * TM + a_off[t]];
+                    gn[t] = Gs[kk * TN + g_off[t]];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], gf[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < Q) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    af[t] = an[t];
+                    gf[t] = gn[t];
+                }
+            }
         }
     }
     float *dst = partial + (size_t)(item * NGRP + grp) * Cin * Cout;
