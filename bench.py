@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="scans per GPU (configs[1]: bs=4)")
     ap.add_argument("--config", default="kitti120k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="build coordinate maps inside the forward pass")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -158,13 +159,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The coordinate maps of batch i+1 are built on a side stream while step i still runs (every timed step
+    # builds one set of maps: the last one prefetches for a step that never comes, the first one was prefetched
+    # by the warm-up).  --no-prefetch builds them inside the forward pass instead.
+    ready = torch.cuda.Event()
+    ready.record()
+    torch.cuda.synchronize()
+
+    def run(i):
+        if args.no_prefetch:
+            return step.training_step(batches[i % 2])
+        return step.training_step(batches[i % 2], prefetch=batches[(i + 1) % 2], prefetch_ready=ready)
+
     for i in range(args.warmup):
-        out = step.training_step(batches[i % 2])
+        out = run(i)
     sync()
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step.training_step(batches[i % 2])
+        out = run(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
     timer.enabled = False

@@ -2,7 +2,10 @@
 
   SoftDICELoss  utils/losses/losses.py:100-109,129-187  (powerize, present-class mask, eps = 0.05)
   DICELoss      utils/losses/losses.py:56-97            (hard one-hot, no mask)
-Same arithmetic order as the reference; only the `.cpu()` round trips (losses.py:72-73,148-149) are gone.
+Same formulas as the reference; the `.cpu()` round trips (losses.py:72-73,148-149) are gone, and rows carrying
+the ignore label are masked (weight 0) instead of being compacted away with boolean indexing: the compaction
+needs the number of valid rows on the host, i.e. a device synchronisation in the middle of every step.  Masked
+rows add exact zeros to every sum, so the loss is the same up to the rounding of a different summation tree.
 """
 import torch
 import torch.nn as nn
@@ -16,6 +19,15 @@ def _dice(prob, target_w, present, powerize):
     return 1 - iou.mean()
 
 
+def _masked_onehot(target, C, ignore_label):
+    """one-hot rows of `target` with all-zero rows where target == ignore_label; (onehot, row weight or None)"""
+    if ignore_label is None:
+        return F.one_hot(target, num_classes=C), None
+    valid = target != ignore_label
+    onehot = F.one_hot(torch.where(valid, target, torch.zeros_like(target)), num_classes=C) * valid.unsqueeze(1)
+    return onehot, valid.unsqueeze(1).to(torch.float32)
+
+
 class SoftDICELoss(nn.Module):
     def __init__(self, ignore_label=None, powerize=True, use_tmask=True, neg_range=False, eps=0.05, is_kitti=False):
         super().__init__()
@@ -25,13 +37,12 @@ class SoftDICELoss(nn.Module):
             ignore_label, powerize, use_tmask, neg_range, eps
 
     def forward(self, output, target):
-        if self.ignore_label is not None:
-            valid = target != self.ignore_label
-            target, output = target[valid], output[valid, :]
         C = output.shape[1]
-        onehot = F.one_hot(target, num_classes=C)
+        onehot, w = _masked_onehot(target, C, self.ignore_label)
         soft = torch.where(onehot == 1, 1 - self.eps, self.eps / (C - 1)).to(torch.float32)
         prob = F.softmax(output, dim=-1)
+        if w is not None:
+            soft, prob = soft * w, prob * w
         present = (onehot.sum(dim=0) > 0).int() if self.use_tmask else torch.ones(C, dtype=torch.int32,
                                                                                   device=output.device)
         loss = _dice(prob, soft, present, self.powerize)
@@ -44,12 +55,11 @@ class DICELoss(nn.Module):
         self.ignore_label, self.powerize, self.use_tmask = ignore_label, powerize, use_tmask
 
     def forward(self, output, target):
-        if self.ignore_label is not None:
-            valid = target != self.ignore_label
-            target, output = target[valid], output[valid, :]
         C = output.shape[1]
-        onehot = F.one_hot(target, num_classes=C)
+        onehot, w = _masked_onehot(target, C, self.ignore_label)
         prob = F.softmax(output, dim=-1)
+        if w is not None:
+            prob = prob * w
         present = (onehot.sum(dim=0) > 0).int() if self.use_tmask else torch.ones(C, dtype=torch.int32,
                                                                                   device=output.device)
         return _dice(prob, onehot, present, self.powerize)

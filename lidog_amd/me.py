@@ -37,14 +37,15 @@ def kernel_offsets(kernel_size, tensor_stride, dilation=1):
     return np.array([(x, y, z) for z in r for y in r for x in r], dtype=np.int32)
 
 
-def _tiles(k_off_host, device):
-    """tile descriptors (tile_k, tile_row0, tile_rows) for 128-row tiles that never straddle an offset"""
+def _tiles_host(k_off_host):
+    """tile descriptors (tile_k, tile_row0, tile_rows) for 128-row tiles that never straddle an offset:
+    (int32 [3, n_tiles] numpy array, n_tiles)"""
     k_off = np.asarray(k_off_host, dtype=np.int64)
     cnt = np.diff(k_off)
     nt = (cnt + TILE_ROWS - 1) // TILE_ROWS
     total = int(nt.sum())
     if total == 0:
-        return torch.zeros((3, 0), dtype=torch.int32, device=device), 0
+        return np.zeros((3, 0), dtype=np.int32), 0
     tile_k = np.repeat(np.arange(len(cnt), dtype=np.int64), nt)
     first = np.repeat(np.cumsum(nt) - nt, nt)
     within = np.arange(total, dtype=np.int64) - first
@@ -54,8 +55,33 @@ def _tiles(k_off_host, device):
     # by output row inside a segment, so these tiles gather (nearly) the same feature rows for different
     # offsets while they are still in L2 instead of re-fetching them K times from HBM.
     order = np.argsort((within + 0.5) / nt[tile_k], kind="stable")
-    desc = np.stack([tile_k[order], row0[order], rows[order]]).astype(np.int32)
+    return np.stack([tile_k[order], row0[order], rows[order]]).astype(np.int32), total
+
+
+def _tiles(k_off_host, device):
+    desc, total = _tiles_host(k_off_host)
     return torch.from_numpy(desc).to(device), total
+
+
+class _Arena:
+    """Host-built int32 tables (tile descriptors, weight-gradient work items) of many maps, shipped to the device
+    in ONE copy; `views()` hands the pieces back in order."""
+
+    def __init__(self):
+        self.parts = []
+
+    def add(self, arr):
+        self.parts.append(np.ascontiguousarray(arr, dtype=np.int32))
+        return len(self.parts) - 1
+
+    def ship(self, device):
+        flat = np.concatenate([a.ravel() for a in self.parts]) if self.parts else np.zeros(0, np.int32)
+        dev = torch.from_numpy(flat).to(device)
+        out, off = [], 0
+        for a in self.parts:
+            out.append(dev[off:off + a.size].view(a.shape))
+            off += a.size
+        return dev, out
 
 
 class _CoordMap:
@@ -68,23 +94,34 @@ class _CoordMap:
 class KernelMap:
     """Rule book of one (in map, out map, kernel) triple; see include/lidog_amd.h:lidog_kernel_map_pairs."""
 
-    def __init__(self, K, n_in, n_out, k_off, k_off_host, pair_in, pair_out, pos_out, pos_in, nbr):
+    def __init__(self, K, n_in, n_out, k_off, k_off_host, pair_in, pair_out, pos_out, pos_in, nbr, tiles=None):
         self.K, self.n_in, self.n_out = K, n_in, n_out
         self.k_off, self.k_off_host = k_off, k_off_host
         self.P = int(k_off_host[-1])
         self.pair_in, self.pair_out, self.pos_out, self.pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
-        self.tiles, self.n_tiles = _tiles(k_off_host, pair_in.device)
+        self.tiles, self.n_tiles = tiles if tiles is not None else _tiles(k_off_host, pair_in.device)
 
 
 class _IdentityMap:
     """tile descriptors / pair lists of a 1x1 convolution over n rows (K = 1, in row == out row)"""
 
-    def __init__(self, n, device):
+    def __init__(self, n, device, tiles=None):
         self.K, self.n_in, self.n_out, self.P = 1, n, n, n
         self.k_off_host = [0, n]
         self.k_off = torch.tensor([0, n], dtype=torch.int64, device=device)
         self.rows = torch.arange(n, dtype=torch.int32, device=device)
-        self.tiles, self.n_tiles = _tiles(self.k_off_host, device)
+        self.tiles, self.n_tiles = tiles if tiles is not None else _tiles(self.k_off_host, device)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """the stream coordinate maps are prepared on when they are built ahead of time (CoordinateManager.prepare)"""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 class CoordinateManager:
@@ -97,6 +134,117 @@ class CoordinateManager:
         self.identity = {}
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
         self.batch_size = None
+        # (map key, Cin, Cout) of every convolution that used this manager, in call order; a later batch of the
+        # same network can be prepared ahead of time from it (CoordinateManager.prepare)
+        self.trace = []
+        self.uniq = None
+        self._ready = None      # event on the side stream once prepare() has finished
+        self._owned = [self.err]  # device tensors created here (handed to the consumer stream by handover())
+
+    def _own(self, *tensors):
+        self._owned.extend(tensors)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    @classmethod
+    def prepare(cls, coordinates, trace, ready_event=None):
+        """Build, on a side stream, the coordinate manager of `coordinates` with every coordinate map, kernel map,
+        tile list and weight-gradient work list named in `trace` (the .trace of a manager that went through the
+        same network).  The host synchronises with the side stream only, so the call overlaps with whatever is
+        queued on the current stream (the previous training step).  `ready_event`: event after which
+        `coordinates` is valid; None = everything queued on the current stream so far.
+        Pass the result as ME.SparseTensor(features, coordinates=..., coordinate_manager=cm)."""
+        _lib.require_gpu(coordinates, "coordinates")
+        dev = coordinates.device
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        if ready_event is not None:
+            side.wait_event(ready_event)
+        else:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cm = cls(dev)
+            cm.uniq, _ = cm.insert(coordinates)
+            cm._own(coordinates)
+            cm.prefetch(trace)
+            cm._ready = torch.cuda.Event()
+            cm._ready.record(side)
+        return cm
+
+    def handover(self):
+        """make the current stream wait for prepare() and tell the allocator that it reads the map tensors"""
+        if self._ready is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._ready)
+        for t in self._owned:
+            t.record_stream(cur)
+        self._ready = None
+
+    def prefetch(self, trace):
+        """Build every map of `trace` that is missing with ONE host synchronisation for all kernel maps and ONE
+        host-to-device copy for all tile / work-item tables (the lazy path costs one of each per map, each with
+        the GPU idle while the host prepares the tables)."""
+        want, shapes = [], {}
+        for key, cin, cout in trace:
+            if key not in shapes:
+                shapes[key] = []
+                want.append(key)
+            if (cin, cout) not in shapes[key]:
+                shapes[key].append((cin, cout))
+        pending = []
+        for key in want:
+            if key[0] == "identity":
+                continue
+            s_in, s_out, ksize, dil = key
+            if key in self.kmaps:
+                continue
+            if s_out != s_in:
+                self.stride(s_in, s_out)
+            pending.append((key, self._kernel_map_launch(key)))
+        hosts = torch.cat([pd[3] for _, pd in pending]).tolist() if pending else []
+        arena, todo, off = _Arena(), [], 0
+        for key, pd in pending:
+            K = pd[0]
+            k_off_host = hosts[off:off + K + 1]
+            off += K + 1
+            desc, n_tiles = _tiles_host(k_off_host)
+            todo.append(("kmap", key, pd, k_off_host, arena.add(desc), n_tiles))
+        for key in want:
+            if key[0] == "identity":
+                n = self.maps[key[1]].n
+                if n not in self.identity:
+                    desc, n_tiles = _tiles_host([0, n])
+                    todo.append(("identity", n, None, [0, n], arena.add(desc), n_tiles))
+        # weight-gradient work items of every (map, Cin, Cout) seen
+        items_todo = []
+        k_off_of = {t[1]: t[3] for t in todo}
+        for key in want:
+            if key[0] == "identity":
+                ident, koh = self.maps[key[1]].n, None
+                koh = k_off_of.get(ident, [0, ident])
+            elif key in k_off_of:
+                koh = k_off_of[key]
+            else:
+                koh = self.kmaps[key].k_off_host
+            seen = set()
+            for cin, cout in shapes[key]:
+                chunk = _wgrad_chunk(int(koh[-1]), cin, cout)
+                if chunk in seen:
+                    continue
+                seen.add(chunk)
+                items, total, item_off = _wgrad_items_host(koh, chunk)
+                items_todo.append((key, chunk, arena.add(items), total, arena.add(item_off)))
+        dev, views = arena.ship(self.device)
+        self._own(dev)
+        for kind, key, pd, k_off_host, slot, n_tiles in todo:
+            if kind == "kmap":
+                self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, (views[slot], n_tiles))
+            else:
+                self.identity[key] = _IdentityMap(key, self.device, (views[slot], n_tiles))
+                self._own(self.identity[key].k_off, self.identity[key].rows)
+        for key, chunk, islot, total, oslot in items_todo:
+            m = self.identity[self.maps[key[1]].n] if key[0] == "identity" else self.kmaps[key]
+            m.__dict__.setdefault("_wgrad_items", {})[chunk] = (views[islot], total, views[oslot])
 
     def _check(self):
         if int(self.err.item()) != 0:
@@ -107,8 +255,8 @@ class CoordinateManager:
         coords = coords.contiguous()
         n = coords.shape[0]
         cap = _lib.load().lidog_hash_capacity(n)
-        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
-        vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+        keys = self._own(torch.empty(cap, dtype=torch.int64, device=self.device))
+        vals = self._own(torch.empty(cap, dtype=torch.int32, device=self.device))
         first = torch.empty(n, dtype=torch.int32, device=self.device)
         n_unique = torch.zeros(1, dtype=torch.int64, device=self.device)
         call("lidog_coords_insert", ptr(coords), n, ptr(keys), ptr(vals), cap, ptr(first), ptr(n_unique),
@@ -127,6 +275,7 @@ class CoordinateManager:
                  ptr(inv), ptr(ws))
             uniq = uniq_full[:m]
             coords = coords[uniq.long()].contiguous()
+            self._own(uniq_full, inv, coords)
         self.maps[1] = _CoordMap(coords, keys, vals, cap)
         return uniq, inv
 
@@ -136,10 +285,10 @@ class CoordinateManager:
         src = self.maps[s_in]
         n = src.n
         cap = _lib.load().lidog_hash_capacity(n)
-        keys = torch.empty(cap, dtype=torch.int64, device=self.device)
-        vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+        keys = self._own(torch.empty(cap, dtype=torch.int64, device=self.device))
+        vals = self._own(torch.empty(cap, dtype=torch.int32, device=self.device))
         p2c = torch.empty(n, dtype=torch.int32, device=self.device)
-        out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        out = self._own(torch.empty((n, 4), dtype=torch.int32, device=self.device))
         n_out = torch.zeros(1, dtype=torch.int64, device=self.device)
         ws = torch.empty(2 * n + 2048, dtype=torch.int32, device=self.device)
         call("lidog_coords_stride", ptr(src.coords), n, int(s_out), ptr(keys), ptr(vals), cap, ptr(p2c), ptr(out),
@@ -152,8 +301,18 @@ class CoordinateManager:
         key = (s_in, s_out, kernel_size, dilation)
         if key in self.kmaps:
             return self.kmaps[key]
+        if s_out != s_in:
+            self.stride(s_in, s_out)
+        pd = self._kernel_map_launch(key)
+        k_off_host = pd[3].tolist()  # one synchronisation per kernel map on this (lazy) path
+        self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, None)
+        return self.kmaps[key]
+
+    def _kernel_map_launch(self, key):
+        """queue the neighbour search and the rule-book compaction of one kernel map (no host synchronisation)"""
+        s_in, s_out, kernel_size, dilation = key
         cin = self.maps[s_in]
-        cout = cin if s_out == s_in else self.stride(s_in, s_out)
+        cout = cin if s_out == s_in else self.maps[s_out]
         offs = kernel_offsets(kernel_size, s_in, dilation)
         K = offs.shape[0]
         n_in, n_out = cin.n, cout.n
@@ -169,11 +328,13 @@ class CoordinateManager:
         ws = torch.empty((nbp + 1) * K + K + 2, dtype=torch.int32, device=self.device)
         call("lidog_kernel_map_pairs", ptr(nbr), n_out, n_in, K, ptr(k_off), ptr(pair_in), ptr(pair_out),
              ptr(pos_out), ptr(pos_in), ptr(ws))
-        k_off_host = k_off.tolist()  # one synchronisation per kernel map (10 per MinkUNet34 forward)
+        self._own(nbr, k_off, pair_in, pair_out, pos_out, pos_in)
+        return (K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr)
+
+    def _kernel_map_finish(self, pd, k_off_host, tiles):
+        K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr = pd
         P = int(k_off_host[-1])
-        km = KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr)
-        self.kmaps[key] = km
-        return km
+        return KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr, tiles)
 
     def identity_map(self, n):
         if n not in self.identity:
@@ -193,9 +354,16 @@ class SparseTensor:
             _lib.require_gpu(features, "features")
             coordinate_manager = CoordinateManager(coordinates.device)
             uniq, _ = coordinate_manager.insert(coordinates)
+            coordinate_manager.uniq = uniq
             if uniq is not None:
                 features = features[uniq.long()]
             coordinate_map_key = 1
+        elif coordinate_manager._ready is not None:
+            # built ahead of time by CoordinateManager.prepare(coordinates, trace) on the side stream
+            coordinate_manager.handover()
+            if coordinate_map_key is None and coordinate_manager.uniq is not None:
+                features = features[coordinate_manager.uniq.long()]
+                coordinate_map_key = 1
         self.coordinate_manager = coordinate_manager
         self.coordinate_map_key = coordinate_map_key if coordinate_map_key is not None else tensor_stride
         self._F = features
@@ -284,11 +452,8 @@ def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter):
 _WGRAD_TARGET_BLOCKS = 2048   # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X
 
 
-def _wgrad_items(m, Cin, Cout):
-    """Work items of the weight gradient: the rule book cut into pair ranges of equal length that never straddle
-    an offset (the centre offset of a 3^3 kernel owns one pair per voxel, corner offsets a few per cent of
-    that: equal splits per offset would leave most workgroups idle behind the centre ones).
-    Returns (items int32 [3, n] on the device, n, item_off int32 [K+1] on the device); cached on the map."""
+def _wgrad_chunk(P, Cin, Cout):
+    """pairs per weight-gradient work item for a rule book of P pairs"""
     def tile(c):
         for t in (128, 96, 64, 32):
             if c % t == 0:
@@ -299,26 +464,40 @@ def _wgrad_items(m, Cin, Cout):
     # (their partial slots are cheap to compute and the final slot sum dominates)
     blocks = _WGRAD_TARGET_BLOCKS if Cin * Cout >= 128 * 128 else _WGRAD_TARGET_BLOCKS // 2
     target = max(1, blocks // tiles)
-    chunk = max(128, -(-m.P // target))
+    chunk = max(128, -(-P // target))
     max_items = max(1, (192 << 20) // (4 * Cin * Cout))             # at most ~192 MB of partial slots
-    chunk = max(chunk, -(-m.P // max_items))
-    chunk = (chunk + 31) // 32 * 32
-    key = chunk
+    chunk = max(chunk, -(-P // max_items))
+    return (chunk + 31) // 32 * 32
+
+
+def _wgrad_items_host(k_off_host, chunk):
+    """(items int32 [3, n] = (k, first pair, end pair), n, item_off int32 [K+1]) as numpy arrays"""
+    k_off = np.asarray(k_off_host, dtype=np.int64)
+    cnt = np.diff(k_off)
+    n_k = (cnt + chunk - 1) // chunk
+    total = int(n_k.sum())
+    item_k = np.repeat(np.arange(len(cnt), dtype=np.int64), n_k)
+    first = np.repeat(np.cumsum(n_k) - n_k, n_k)
+    within = np.arange(total, dtype=np.int64) - first
+    p0 = k_off[item_k] + within * chunk
+    p1 = np.minimum(p0 + chunk, k_off[item_k + 1])
+    return (np.stack([item_k, p0, p1]).astype(np.int32), total,
+            np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32))
+
+
+def _wgrad_items(m, Cin, Cout):
+    """Work items of the weight gradient: the rule book cut into pair ranges of equal length that never straddle
+    an offset (the centre offset of a 3^3 kernel owns one pair per voxel, corner offsets a few per cent of
+    that: equal splits per offset would leave most workgroups idle behind the centre ones).
+    Returns (items int32 [3, n] on the device, n, item_off int32 [K+1] on the device); cached on the map
+    (CoordinateManager.prefetch fills the cache ahead of the backward pass)."""
+    chunk = _wgrad_chunk(m.P, Cin, Cout)
     cache = m.__dict__.setdefault("_wgrad_items", {})
-    if key not in cache:
-        k_off = np.asarray(m.k_off_host, dtype=np.int64)
-        cnt = np.diff(k_off)
-        n_k = (cnt + chunk - 1) // chunk
-        total = int(n_k.sum())
-        item_k = np.repeat(np.arange(len(cnt), dtype=np.int64), n_k)
-        first = np.repeat(np.cumsum(n_k) - n_k, n_k)
-        within = np.arange(total, dtype=np.int64) - first
-        p0 = k_off[item_k] + within * chunk
-        p1 = np.minimum(p0 + chunk, k_off[item_k + 1])
-        items = torch.from_numpy(np.stack([item_k, p0, p1]).astype(np.int32)).to(m.k_off.device)
-        item_off = torch.from_numpy(np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)).to(m.k_off.device)
-        cache[key] = (items, total, item_off)
-    return cache[key]
+    if chunk not in cache:
+        items, total, item_off = _wgrad_items_host(m.k_off_host, chunk)
+        dev = m.k_off.device
+        cache[chunk] = (torch.from_numpy(items).to(dev), total, torch.from_numpy(item_off).to(dev))
+    return cache[chunk]
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -550,9 +729,11 @@ class _ConvBase(nn.Module):
         cm, s_in = x.coordinate_manager, x.coordinate_map_key
         if self.kernel_volume == 1 and self.stride == 1:
             m, s_out, swap, single_out, single_in = cm.identity_map(x.F.shape[0]), s_in, False, True, True
+            cm.trace.append((("identity", s_in), self.in_channels, self.out_channels))
         elif not self.transposed:
             s_out = s_in * self.stride
             m = cm.kernel_map(s_in, s_out, self.kernel_size, self.dilation)
+            cm.trace.append(((s_in, s_out, self.kernel_size, self.dilation), self.in_channels, self.out_channels))
             swap, single_out = False, False
             single_in = self.stride == self.kernel_size and self.stride > 1  # non-overlapping windows
         else:
@@ -560,6 +741,7 @@ class _ConvBase(nn.Module):
                 raise ValueError("transposed convolution must land on an existing finer coordinate map")
             s_out = s_in // self.stride
             m = cm.kernel_map(s_out, s_in, self.kernel_size, self.dilation)
+            cm.trace.append(((s_out, s_in, self.kernel_size, self.dilation), self.in_channels, self.out_channels))
             swap, single_in = True, False
             single_out = self.stride == self.kernel_size and self.stride > 1
         out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in, stats)

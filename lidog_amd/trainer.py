@@ -165,7 +165,37 @@ class FlatAdam:
         self.steps, self.lr = sd["steps"], sd["lr"]
 
 
-class LiDOGStep:
+class _CoordinatePrefetch:
+    """Coordinate maps of the NEXT batch are built on a side stream while the GPU still works on the current step
+    (the host runs ahead of the GPU by then): `training_step(batch, prefetch=next_batch)`.  What to build is the
+    trace of map uses recorded by the first forward pass; it is the data-loader-side half of the reference's step
+    (ME builds its maps inside the forward call) moved off the critical path, not skipped."""
+
+    _trace = None
+
+    @staticmethod
+    def _coords(batch):
+        return batch["coords_int"] if "coords_int" in batch else batch["source_coordinates0"].int()
+
+    def _sparse_input(self, batch):
+        coords = self._coords(batch)
+        hit = self.__dict__.setdefault("_prepared", {}).pop(id(coords), None)
+        if hit is not None and hit[0] is coords:
+            st = ME.SparseTensor(features=batch["source_features0"], coordinates=coords, coordinate_manager=hit[1])
+        else:
+            st = ME.SparseTensor(coordinates=coords, features=batch["source_features0"])
+        self._last_manager = st.coordinate_manager
+        return st
+
+    def _after_step(self, prefetch, prefetch_ready):
+        self._trace = self._last_manager.trace
+        if prefetch is not None and "coords_int" in prefetch:
+            coords = prefetch["coords_int"]
+            self.__dict__.setdefault("_prepared", {})[id(coords)] = \
+                (coords, ME.CoordinateManager.prepare(coords, self._trace, prefetch_ready))
+
+
+class LiDOGStep(_CoordinatePrefetch):
     """PLTTrainer2D.training_step without the host round trips (coords / logits stay in HBM)."""
 
     def __init__(self, model, optimizer, source_weights=(0.5, 0.5), warmup_epochs=0, num_classes=7, ignore_label=-1):
@@ -175,8 +205,7 @@ class LiDOGStep:
         self.bev_criterion = DICELoss(ignore_label=ignore_label)
 
     def forward_loss(self, batch, epoch=0):
-        coords = batch["coords_int"] if "coords_int" in batch else batch["source_coordinates0"].int()
-        st = ME.SparseTensor(coordinates=coords, features=batch["source_features0"])
+        st = self._sparse_input(batch)
         sem, bev = self.model(st, is_train=True)
         bev_loss = 0.0
         for key, lab in batch["source_bev_labels0"].items():
@@ -190,29 +219,32 @@ class LiDOGStep:
             total = bev_loss
         return total, sem_loss, bev_loss, sem
 
-    def training_step(self, batch, epoch=0):
+    def training_step(self, batch, epoch=0, prefetch=None, prefetch_ready=None):
+        """`prefetch`: the batch of the NEXT call (its coordinate maps are built while this step still runs on
+        the GPU); `prefetch_ready`: event after which its coordinates are valid (None: everything queued so far)"""
         total, sem_loss, bev_loss, _ = self.forward_loss(batch, epoch)
         self.opt.zero_grad()
         total.backward()
         self.opt.step()
+        self._after_step(prefetch, prefetch_ready)
         return {"loss": total.detach(), "sem_loss": sem_loss.detach(), "bev_loss": bev_loss.detach()}
 
 
-class SourceStep:
+class SourceStep(_CoordinatePrefetch):
     """PLTTrainer.training_step (train_source.py / Mix3D): MinkUNet34, SoftDICE only."""
 
     def __init__(self, model, optimizer, ignore_label=-1):
         self.model, self.opt = model, optimizer
         self.criterion = SoftDICELoss(ignore_label=ignore_label)
 
-    def training_step(self, batch, epoch=0):
-        coords = batch["coords_int"] if "coords_int" in batch else batch["source_coordinates0"].int()
-        st = ME.SparseTensor(coordinates=coords, features=batch["source_features0"])
+    def training_step(self, batch, epoch=0, prefetch=None, prefetch_ready=None):
+        st = self._sparse_input(batch)
         out = self.model(st, is_seg=True)
         loss = self.criterion(out.F, batch["source_sem_labels0"].long())
         self.opt.zero_grad()
         loss.backward()
         self.opt.step()
+        self._after_step(prefetch, prefetch_ready)
         return {"loss": loss.detach()}
 
 

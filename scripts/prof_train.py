@@ -8,8 +8,9 @@ torch.manual_seed(1234)
 model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=50.0).cuda().train()
 step = LiDOGStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4))
 batches = [synth.make_batch(range(4 * i, 4 * i + 4), "kitti120k", "cuda") for i in range(2)]
+READY = torch.cuda.Event(); READY.record(); torch.cuda.synchronize()
 n = int(os.environ.get("STEPS", 5))
 for i in range(n):
-    step.training_step(batches[i % 2])
+    step.training_step(batches[i % 2], prefetch=None if os.environ.get('NO_PREFETCH') else batches[(i + 1) % 2], prefetch_ready=READY)
 torch.cuda.synchronize()
 print("steps", n)
