@@ -173,9 +173,25 @@ int lidog_conv2d_fwd(const float *x, const float *w, const float *bias, int32_t 
 int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, int32_t Cin, int32_t H, int32_t W,
                        int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *gx, float *ws,
                        void *stream);
+/* ws: split-K partial slabs, summed in order (no atomics).  k3 s2 p1: as many slabs of Cout*Cin*9 floats as fit
+ * (32 are enough); k1: 4*B slabs of Cout*Cin + Cout floats. */
 int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, int32_t Cin, int32_t H, int32_t W,
                        int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *gw, float *gbias,
                        float *ws, int64_t ws_floats, void *stream);
+
+/* ------------------------------------------------------------------ DICE losses
+ * utils/losses/losses.py:56-97 (DICELoss: soft = 0) and :100-187 (SoftDICELoss: soft = 1, label smoothing eps,
+ * powerize, present-class mask), as called by trainer_lighting_2d.py:172-190.  logits [n, C] float32 (C in
+ * {2, 7, 8, 16}), target [n] int64; rows with target == ignore_label are skipped when has_ignore != 0.
+ * fwd: loss[0] = 1 - mean present-class DICE + offset (offset = -1 for neg_range); coef [2C] receives the
+ * per-class gradient coefficients bwd needs; ws: lidog_dice_ws(C) doubles.  bwd: glogits = d loss / d logits * gout[0]. */
+int64_t lidog_dice_ws(int32_t C);
+int lidog_dice_fwd(const float *logits, const int64_t *target, int64_t n, int32_t C, int64_t ignore_label,
+                   int32_t has_ignore, float eps, int32_t soft, int32_t powerize, int32_t use_tmask, float offset,
+                   double *ws, float *loss, float *coef, void *stream);
+int lidog_dice_bwd(const float *logits, const int64_t *target, int64_t n, int32_t C, int64_t ignore_label,
+                   int32_t has_ignore, float eps, int32_t soft, int32_t powerize, const float *coef, const float *gout,
+                   float *glogits, void *stream);
 
 /* ------------------------------------------------------------------ data path next to the hot path
  * ME.utils.sparse_quantize (utils/datasets/semantickitti_bev.py:232-238) = lidog_voxel_floor +

@@ -47,9 +47,13 @@ SIGNATURES = {
     "lidog_voxel_floor": [_p, _i64, _f, _f, _f, _i32, _p, _p],
     "lidog_label_vote": [_p, _p, _p, _i64, _i64, _i32, _p, _p],
     "lidog_bev_label_raster": [_p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
+    "lidog_dice_ws": [_i32],
+    "lidog_dice_fwd": [_p, _p, _i64, _i32, _i64, _i32, _f, _i32, _i32, _i32, _f, _p, _p, _p, _p],
+    "lidog_dice_bwd": [_p, _p, _i64, _i32, _i64, _i32, _f, _i32, _i32, _p, _p, _p, _p],
     "lidog_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i32, _f, _p],
 }
-_RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64}
+_RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
+             "lidog_dice_ws": _i64}
 
 _lib = None
 

@@ -385,11 +385,11 @@ __global__ __launch_bounds__(256) void k_repack_dgrad(const float *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_sum_splits(const float *__restrict__ partial, int64_t n, int splits,
-                                                    float *__restrict__ out) {
+                                                    int64_t stride, float *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float acc = partial[i];
-    for (int s = 1; s < splits; ++s) acc += partial[(size_t)s * n + i];
+    for (int s = 1; s < splits; ++s) acc += partial[(size_t)s * stride + i];
     out[i] = acc;
 }
 
@@ -433,24 +433,30 @@ __global__ __launch_bounds__(256) void k_pw_dgrad(const float *__restrict__ gY, 
     }
 }
 
-// block per ci: gW[co][ci] = sum_{b,pix} gY[b][co][pix] * X[b][ci][pix]; block ci == 0 also writes gbias
-__global__ __launch_bounds__(256) void k_pw_wgrad(const float *__restrict__ X, const float *__restrict__ gY, int Bn,
-                                                  int Cin, int Cout, int64_t HW, float *__restrict__ gW,
-                                                  float *__restrict__ gbias) {
+// gW[co][ci] = sum_{b,pix} gY[b][co][pix] * X[b][ci][pix], gbias[co] = sum gY[b][co][pix].
+// Block (ci, s): slice s = (image b, quarter of its pixels); partial[s][co*Cin + ci] (and partial[s][Cout*Cin + co]
+// from the ci == 0 blocks) in double per block, summed over s in order by k_sum_splits: no atomics.
+#define PW_QUARTERS 4
+__global__ __launch_bounds__(256) void k_pw_wgrad(const float *__restrict__ X, const float *__restrict__ gY, int Cin,
+                                                  int Cout, int HW, float *__restrict__ partial) {
     __shared__ double red[2 * PW_MAXCO][4];
-    const int ci = blockIdx.x;
+    const int ci = blockIdx.x, s = blockIdx.y;
+    const int b = s / PW_QUARTERS, q = s % PW_QUARTERS;
+    const int chunk = (HW + PW_QUARTERS - 1) / PW_QUARTERS;
+    const int e0 = q * chunk, e1 = e0 + chunk < HW ? e0 + chunk : HW;
+    const float *x = X + ((size_t)b * Cin + ci) * HW;
+    const float *g = gY + (size_t)b * Cout * HW;
     double acc[PW_MAXCO], accb[PW_MAXCO];
 #pragma unroll
     for (int co = 0; co < PW_MAXCO; ++co) { acc[co] = 0; accb[co] = 0; }
-    for (int64_t e = threadIdx.x; e < (int64_t)Bn * HW; e += 256) {
-        int64_t b = e / HW, pix = e - b * HW;
-        float x = X[((size_t)b * Cin + ci) * HW + pix];
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        float xv = x[e];
 #pragma unroll
         for (int co = 0; co < PW_MAXCO; ++co)
             if (co < Cout) {
-                float g = gY[((size_t)b * Cout + co) * HW + pix];
-                acc[co] += (double)g * (double)x;
-                accb[co] += (double)g;
+                float gv = g[(size_t)co * HW + e];
+                acc[co] += (double)gv * (double)xv;
+                accb[co] += (double)gv;
             }
     }
 #pragma unroll
@@ -463,10 +469,11 @@ __global__ __launch_bounds__(256) void k_pw_wgrad(const float *__restrict__ X, c
     __syncthreads();
     if (threadIdx.x < Cout) {
         int co = threadIdx.x;
-        gW[co * Cin + ci] = (float)(red[co][0] + red[co][1] + red[co][2] + red[co][3]);
-        if (ci == 0 && gbias)
-            gbias[co] = (float)(red[PW_MAXCO + co][0] + red[PW_MAXCO + co][1] + red[PW_MAXCO + co][2] +
-                                red[PW_MAXCO + co][3]);
+        float *dst = partial + (size_t)s * (Cout * Cin + Cout);
+        dst[co * Cin + ci] = (float)(red[co][0] + red[co][1] + red[co][2] + red[co][3]);
+        if (ci == 0)
+            dst[Cout * Cin + co] = (float)(red[PW_MAXCO + co][0] + red[PW_MAXCO + co][1] + red[PW_MAXCO + co][2] +
+                                           red[PW_MAXCO + co][3]);
     }
 }
 
@@ -559,7 +566,15 @@ extern "C" int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, in
     hipStream_t st = (hipStream_t)stream;
     if (ksize == 1) {
         LIDOG_REQUIRE(stride == 1 && pad == 0 && Cout <= PW_MAXCO, "conv2d_wgrad: 1x1 path needs stride 1, Cout <= 8");
-        k_pw_wgrad<<<(unsigned)Cin, 256, 0, st>>>(x, gy, B, Cin, Cout, (int64_t)H * W, gw, gbias);
+        const int splits = B * PW_QUARTERS;
+        const int64_t slab = (int64_t)Cout * Cin + Cout;
+        LIDOG_REQUIRE(ws != nullptr && ws_floats >= splits * slab,
+                      "conv2d_wgrad: 1x1 path needs a workspace of %lld floats", (long long)(splits * slab));
+        LIDOG_REQUIRE((int64_t)H * W < ((int64_t)1 << 31), "conv2d_wgrad: image too large");
+        if (B == 0 || H * W == 0) return 0;
+        k_pw_wgrad<<<dim3((unsigned)Cin, (unsigned)splits), 256, 0, st>>>(x, gy, Cin, Cout, H * W, ws);
+        k_sum_splits<<<(unsigned)cdiv64((int64_t)Cout * Cin, 256), 256, 0, st>>>(ws, (int64_t)Cout * Cin, splits, slab, gw);
+        if (gbias) k_sum_splits<<<1, 256, 0, st>>>(ws + (int64_t)Cout * Cin, Cout, splits, slab, gbias);
         LIDOG_LAUNCH_CHECK();
         return 0;
     }
@@ -585,7 +600,7 @@ extern "C" int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, in
     p.D = (splits == 1) ? gw : ws;
     dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), (unsigned)splits);
     k_conv_wgrad<<<grid, 256, 0, st>>>(p);
-    if (splits > 1) k_sum_splits<<<(unsigned)cdiv64(slab, 256), 256, 0, st>>>(ws, slab, splits, gw);
+    if (splits > 1) k_sum_splits<<<(unsigned)cdiv64(slab, 256), 256, 0, st>>>(ws, slab, splits, slab, gw);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

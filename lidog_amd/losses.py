@@ -11,6 +11,46 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+from ._lib import call, ptr
+
+_FUSED_CLASSES = (2, 7, 8, 16)
+
+
+class _DiceFn(torch.autograd.Function):
+    """csrc/losses.hip: softmax + the per-class sums in one pass, the gradient in one pass"""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_label, eps, soft, powerize, use_tmask, offset):
+        logits, target = logits.contiguous(), target.contiguous()
+        if target.dtype != torch.int64:
+            target = target.long()
+        n, C = logits.shape
+        dev = logits.device
+        ws = torch.empty(_lib.load().lidog_dice_ws(C), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        has_ignore = ignore_label is not None
+        cfg = (n, C, int(ignore_label) if has_ignore else 0, 1 if has_ignore else 0, float(eps), 1 if soft else 0,
+               1 if powerize else 0)
+        call("lidog_dice_fwd", ptr(logits), ptr(target), *cfg, 1 if use_tmask else 0, float(offset), ptr(ws),
+             ptr(loss), ptr(coef))
+        ctx.save_for_backward(logits, target, coef)
+        ctx.cfg = cfg
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, coef = ctx.saved_tensors
+        g = torch.empty_like(logits)
+        call("lidog_dice_bwd", ptr(logits), ptr(target), *ctx.cfg, ptr(coef), ptr(gout.contiguous()), ptr(g))
+        return g, None, None, None, None, None, None, None
+
+
+def _fused(output):
+    return output.is_cuda and output.dim() == 2 and output.shape[1] in _FUSED_CLASSES and \
+        output.dtype == torch.float32
+
 
 def _dice(prob, target_w, present, powerize):
     inter = (prob * target_w).sum(dim=0)
@@ -37,6 +77,10 @@ class SoftDICELoss(nn.Module):
             ignore_label, powerize, use_tmask, neg_range, eps
 
     def forward(self, output, target):
+        if _fused(output):
+            return _DiceFn.apply(output, target, self.ignore_label, self.eps, True, self.powerize, self.use_tmask,
+                                 -1.0 if self.neg_range else 0.0)
+        # host-side formula (CPU tensors in unit tests, unusual class counts)
         C = output.shape[1]
         onehot, w = _masked_onehot(target, C, self.ignore_label)
         soft = torch.where(onehot == 1, 1 - self.eps, self.eps / (C - 1)).to(torch.float32)
@@ -55,6 +99,8 @@ class DICELoss(nn.Module):
         self.ignore_label, self.powerize, self.use_tmask = ignore_label, powerize, use_tmask
 
     def forward(self, output, target):
+        if _fused(output):
+            return _DiceFn.apply(output, target, self.ignore_label, 0.0, False, self.powerize, self.use_tmask, 0.0)
         C = output.shape[1]
         onehot, w = _masked_onehot(target, C, self.ignore_label)
         prob = F.softmax(output, dim=-1)
