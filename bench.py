@@ -15,6 +15,10 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# Four HIP streams are busy in a data-parallel step (compute, RCCL, weight gradients, next batch's coordinate
+# maps); with the runtime's default of 4 hardware queues two of them can land on the same queue and serialise
+# (measured: the weight-gradient stream then overlaps nothing).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -125,11 +129,17 @@ def main():
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    # LIDOG_BENCH_SINGLE_RANK_DP=1: a ONE-rank RCCL process group with every data-parallel code path switched on
+    # (SyncBN statistics all-reduces, gradient buckets, second backward stream): the collectives of the N > 1
+    # runs exercised against the real RCCL library on a 1-GPU box
+    single_dp = world == 1 and os.environ.get("LIDOG_BENCH_SINGLE_RANK_DP") == "1"
+    if world > 1 or single_dp:
         if one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import lidog_amd
@@ -137,6 +147,9 @@ def main():
     from lidog_amd import synth
     from lidog_amd.trainer import FlatAdam, LiDOGStep, setup_data_parallel
 
+    if single_dp:
+        from lidog_amd.trainer import GradientBuckets
+        ME.MinkowskiSyncBatchNorm.single_rank = GradientBuckets.single_rank = True
     timer = GemmTimer()
     if not args.no_kernel_timing:
         timer.wrap(ME)
@@ -155,7 +168,7 @@ def main():
     n_vox = sum(b["coords_int"].shape[0] for b in batches) / (2 * args.batch)
 
     def sync():
-        if world > 1:
+        if world > 1 or single_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -207,7 +220,7 @@ def main():
                "config": {"workload": f"train_lidog.py Synth4D-kitti-like MinkUNet34 + BEV head (B=50 m, 0.05 m voxels), "
                                       f"bs={args.batch}/GPU, {args.config} synthetic scans, "
                                       f"{n_vox:.0f} voxels/scan, SoftDICE+DICE, Adam", "global_batch": world * args.batch,
-                          "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+                          "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else "")},
                "loss": loss}
         if eval_rate is not None:
             res["forward_only_scans_per_s"] = eval_rate
@@ -236,7 +249,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.config)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or single_dp:
         dist.barrier()
         dist.destroy_process_group()
 

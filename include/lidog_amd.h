@@ -98,7 +98,10 @@ int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K,
  * partial_ws: lidog_sconv_reduce_stats_ws(n, C) doubles.  C % 4 == 0. */
 int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C);
 int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
-                             float *out, double *sums, double *partial_ws, void *stream);
+                             float *out, double *sums, double *partial_ws, double count, float eps, float momentum,
+                             float *mean, float *invstd, float *running_mean, float *running_var, void *stream);
+/* count / eps / momentum / mean / invstd / running_*: as for lidog_bn_stats below (the last kernel of the
+ * reduction also stores the row count behind the sums and, when mean != NULL, finalises the statistics). */
 
 /* gW[k] = sum over the pairs p of offset k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
  * The pair list is cut on the host into work items of (nearly) equal length that never straddle an offset:
@@ -125,10 +128,14 @@ int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout,
  * ME.MinkowskiReLU (:124).  layout: x[n, C] when hw == 1; NCHW with hw = H*W otherwise
  * (nn.BatchNorm2d of utils/models/conv2d.py:18,21). */
 
-/* per-channel sums in double: sums[2*C] = (sum x, sum x^2), overwritten.  ws: lidog_bn_reduce_ws(C, hw) doubles of
- * scratch (per-workgroup partials added in a fixed order; 0 = not needed, ws may be NULL) */
+/* per-channel sums in double: sums[0..2C) = (sum x, sum x^2), overwritten.  ws: lidog_bn_reduce_ws(C, hw) doubles of
+ * scratch (per-workgroup partials added in a fixed order; 0 = not needed, ws may be NULL).
+ * count > 0: also stored at sums[2*C] (SyncBatchNorm all-reduces the row count together with the sums).
+ * mean != NULL: lidog_bn_finalize(sums, count, ...) is folded into the same launch (local BatchNorm). */
 int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw);
-int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws, void *stream);
+int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws, double count,
+                   float eps, float momentum, float *mean, float *invstd, float *running_mean, float *running_var,
+                   void *stream);
 /* mean/invstd from sums and count; updates running stats (momentum, unbiased var) when not NULL.
  * count <= 0: the count is read from sums[2*C] on the device (SyncBatchNorm all-reduces it with the sums);
  * the same convention holds for lidog_bn_bwd_apply. */
@@ -137,10 +144,12 @@ int lidog_bn_finalize(const double *sums, double count, int32_t C, float eps, fl
 /* y = (x - mean) * invstd * w + b (+ residual) (relu).  In-place (y == x) allowed. */
 int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean, const float *invstd,
                    const float *w, const float *b, const float *residual, int32_t relu, float *y, void *stream);
-/* backward reduce: sums[2*C] = (sum dy', sum dy'*xhat) with dy' = dy * (y > 0) when relu_y != NULL; ws as above */
+/* backward reduce: sums[0..2C) = (sum dy', sum dy'*xhat) with dy' = dy * (y > 0) when relu_y != NULL; ws as above;
+ * count > 0: stored at sums[2*C]; db / dw != NULL: the LOCAL parameter gradients (float copies of the two sums) */
 int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
-                        const float *mean, const float *invstd, double *sums, double *ws, void *stream);
-/* dx = w*invstd*(dy' - s0/count - xhat*s1/count); dres = dy' when dres != NULL; dw = s1, db = s0 */
+                        const float *mean, const float *invstd, double *sums, double *ws, double count, float *dw,
+                        float *db, void *stream);
+/* dx = w*invstd*(dy' - s0/count - xhat*s1/count); dres = dy' when dres != NULL; dw = s1, db = s0 when != NULL */
 int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                        const float *mean, const float *invstd, const float *w, const double *sums, double count,
                        float *dx, float *dres, float *dw, float *db, void *stream);

@@ -7,8 +7,14 @@ Public surface:
   lidog_amd.losses        SoftDICELoss / DICELoss on the device
   lidog_amd.trainer       training step, Adam, RCCL data parallelism
 """
-from . import me, bev, losses  # noqa: F401
-from .minkunet import make_models
+import os as _os
+
+# compute, RCCL, weight-gradient and coordinate-map streams must not share a hardware queue (the runtime's default
+# is 4 queues for all streams of a process); only effective when set before the HIP runtime starts
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import me, bev, losses  # noqa: E402,F401
+from .minkunet import make_models  # noqa: E402
 
 _models = make_models(me, bev.Encoder2D, bev.sparse2super)
 MinkUNet34 = _models.MinkUNet34

@@ -23,17 +23,17 @@ SIGNATURES = {
     "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p],
     "lidog_sconv_reduce_stats_ws": [_i64, _i32],
-    "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p],
+    "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
     "lidog_set_sparse_core": [_i32],
     "lidog_get_sparse_core": [],
     "lidog_transpose_kernel": [_p, _i32, _i32, _i32, _p, _p],
     "lidog_bn_reduce_ws": [_i32, _i64],
-    "lidog_bn_stats": [_p, _i64, _i32, _i64, _p, _p, _p],
+    "lidog_bn_stats": [_p, _i64, _i32, _i64, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_bn_finalize": [_p, _d, _i32, _f, _f, _p, _p, _p, _p, _p],
     "lidog_bn_apply": [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
-    "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p],
+    "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p],
     "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
     "lidog_relu_fwd": [_p, _i64, _p, _p],
     "lidog_relu_bwd": [_p, _p, _i64, _p, _p],

@@ -91,20 +91,40 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
     }
 }
 
-// sums[c] = sum over blocks (ascending, fixed tree) of partial[b][c]; one workgroup per 4 channels
-__global__ __launch_bounds__(256) void k_partials_sum(const double *__restrict__ partial, int nb, int C2,
-                                                      double *__restrict__ sums) {
+// sums[col] = sum over blocks (ascending, fixed tree) of partial[b][col] for the 2C columns (C first sums, C second
+// sums).  One workgroup per channel pair, both sums of a channel in the same workgroup, so what follows the
+// reduction rides in the same launch instead of a microsecond-sized kernel of its own per layer:
+//   count > 0   -> sums[2C] = count   (SyncBatchNorm all-reduces the row count together with the sums)
+//   fin.mean    -> mean / invstd / running statistics from (sum x, sum x^2) and count  (= k_bn_finalize)
+//   fin.db / dw -> float copies of (first sums, second sums)                            (= k_bn_param_grads)
+__device__ __forceinline__ void bn_finalize_channel(double sx, double sxx, double count, int c, const BnFinish &fin) {
+    double m = sx / count;
+    double var = sxx / count - m * m;
+    if (var < 0) var = 0;
+    fin.mean[c] = (float)m;
+    fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
+    if (fin.running_mean) {
+        double unb = (count > 1) ? var * count / (count - 1) : var;
+        fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
+        fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unb;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sums_finish(const double *__restrict__ partial, int nb, int C,
+                                                     double *__restrict__ sums, double count, BnFinish fin) {
     __shared__ double red[256];
     const int cl = threadIdx.x & 3, bl = threadIdx.x >> 2;
-    const int c = blockIdx.x * 4 + cl;
+    const int ch = blockIdx.x * 2 + (cl & 1), half = cl >> 1;
+    const int C2 = 2 * C, col = half * C + ch;
+    const bool valid = ch < C;
     double s0 = 0, s1 = 0;
-    if (c < C2) {
+    if (valid) {
         int b = bl;
         for (; b + 64 < nb; b += 128) {
-            s0 += partial[(size_t)b * C2 + c];
-            s1 += partial[(size_t)(b + 64) * C2 + c];
+            s0 += partial[(size_t)b * C2 + col];
+            s1 += partial[(size_t)(b + 64) * C2 + col];
         }
-        if (b < nb) s0 += partial[(size_t)b * C2 + c];
+        if (b < nb) s0 += partial[(size_t)b * C2 + col];
     }
     red[threadIdx.x] = s0 + s1;
     __syncthreads();
@@ -113,7 +133,29 @@ __global__ __launch_bounds__(256) void k_partials_sum(const double *__restrict__
         if (bl < d) red[threadIdx.x] += red[threadIdx.x + d * 4];
         __syncthreads();
     }
-    if (bl == 0 && c < C2) sums[c] = red[cl];
+    if (bl == 0 && valid) {
+        sums[col] = red[cl];
+        if (fin.db && half == 0) fin.db[ch] = (float)red[cl];
+        if (fin.dw && half == 1) fin.dw[ch] = (float)red[cl];
+        if (fin.mean && half == 0) bn_finalize_channel(red[cl], red[cl + 2], count, ch, fin);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count > 0) sums[C2] = count;
+}
+
+int lidog_launch_sums_finish(const double *partial, int nb, int C, double *sums, double count, BnFinish fin,
+                             hipStream_t st) {
+    k_sums_finish<<<(unsigned)((C + 1) / 2), 256, 0, st>>>(partial, nb, C, sums, count, fin);
+    return 0;
+}
+
+// the same three follow-ups for the reductions that accumulate with atomics (NCHW planes, C % 4 != 0)
+__global__ void k_sums_post(double *__restrict__ sums, int C, double count, BnFinish fin) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && count > 0) sums[2 * C] = count;
+    if (c >= C) return;
+    if (fin.db) fin.db[c] = (float)sums[c];
+    if (fin.dw) fin.dw[c] = (float)sums[C + c];
+    if (fin.mean) bn_finalize_channel(sums[c], sums[C + c], count, c, fin);
 }
 
 // generic layout (NCHW planes, or [n,C] with C % 4 != 0 as hw = 1 "planes" of strided access)
@@ -182,8 +224,9 @@ static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4
 
 template <int MODE>
 static int launch_colreduce(const float *x, const float *dy, const float *ry, int64_t n, int C, int64_t hw,
-                            const float *mean, const float *invstd, double *sums, double *ws, hipStream_t st) {
-    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) == hipSuccess ? 0 : 1;
+                            const float *mean, const float *invstd, double *sums, double *ws, double count,
+                            BnFinish fin, hipStream_t st) {
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     if (colreduce_uses_partials(C, hw)) {
         LIDOG_REQUIRE(ws != nullptr, "bn reduce: workspace of lidog_bn_reduce_ws() doubles required");
         int C4 = C / 4, RB = 256 / C4;
@@ -192,7 +235,7 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
         if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
         k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
                                                             n, C4, mean, invstd, ws);
-        k_partials_sum<<<(unsigned)cdiv64(2 * C, 4), 256, 0, st>>>(ws, (int)nb, 2 * C, sums);
+        lidog_launch_sums_finish(ws, (int)nb, C, sums, count, fin, st);
     } else {
         // atomic variants accumulate: start from zero
         if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) return 1;
@@ -207,6 +250,8 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
             k_colreduce_plane<MODE><<<dim3((unsigned)planes, (unsigned)chunks), 256, 0, st>>>(x, dy, ry, hw, C, mean,
                                                                                               invstd, sums);
         }
+        if (count > 0 || fin.mean || fin.dw || fin.db)
+            k_sums_post<<<(C + 127) / 128, 128, 0, st>>>(sums, C, count, fin);
     }
     LIDOG_LAUNCH_CHECK();
     return 0;
@@ -216,15 +261,20 @@ extern "C" int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw) {
     return colreduce_uses_partials(C, hw) ? (int64_t)COLREDUCE_MAX_BLOCKS * 2 * C : 0;
 }
 
-extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws,
-                              void *stream) {
-    return launch_colreduce<0>(x, nullptr, nullptr, n, C, hw, nullptr, nullptr, sums, ws, (hipStream_t)stream);
+extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws, double count,
+                              float eps, float momentum, float *mean, float *invstd, float *running_mean,
+                              float *running_var, void *stream) {
+    LIDOG_REQUIRE(mean == nullptr || count > 0, "bn_stats: finalising needs the row count");
+    BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
+    return launch_colreduce<0>(x, nullptr, nullptr, n, C, hw, nullptr, nullptr, sums, ws, count, fin,
+                               (hipStream_t)stream);
 }
 
 extern "C" int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C,
                                    int64_t hw, const float *mean, const float *invstd, double *sums, double *ws,
-                                   void *stream) {
-    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, ws, (hipStream_t)stream);
+                                   double count, float *dw, float *db, void *stream) {
+    BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
+    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, ws, count, fin, (hipStream_t)stream);
 }
 
 __global__ void k_bn_finalize(const double *__restrict__ sums, double count, int C, float eps, float momentum,
@@ -401,7 +451,7 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
         k_bn_bwd_apply<<<ew_grid(total), 256, 0, st>>>(dy, x, relu_y, total, C, hw, mean, invstd, w, sums,
                                                        count > 0 ? 1.0 / count : -1.0,
                                                        dx, dres);
-    k_bn_param_grads<<<(C + 127) / 128, 128, 0, st>>>(sums, C, dw, db);
+    if (dw || db) k_bn_param_grads<<<(C + 127) / 128, 128, 0, st>>>(sums, C, dw, db);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

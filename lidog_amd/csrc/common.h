@@ -29,6 +29,16 @@ void lidog_set_error(const char *fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// What the last kernel of a per-channel (sum, sum) reduction does besides writing the sums (bn.hip:k_sums_finish):
+// BatchNorm statistics finalisation (mean != NULL) and/or float copies of the two sums (dw / db != NULL).
+struct BnFinish {
+    float eps, momentum;
+    float *mean, *invstd, *running_mean, *running_var;
+    float *dw, *db;
+};
+int lidog_launch_sums_finish(const double *partial, int nb, int C, double *sums, double count, BnFinish fin,
+                             hipStream_t st);
+
 // 63-bit packed coordinate key: batch 12 bits, x/y/z 17 bits each (biased by 65536).
 #define LIDOG_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 

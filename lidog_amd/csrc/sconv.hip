@@ -304,7 +304,7 @@ extern "C" int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n,
 }
 
 // Same reduction with the BatchNorm statistics of the result folded in: every workgroup also emits its partial
-// (sum x, sum x^2) per channel in fp64 to partial[block][2C]; k_stats_finish adds the partials in block order
+// (sum x, sum x^2) per channel in fp64 to partial[block][2C]; bn.hip:k_sums_finish adds the partials in block order
 // (no atomics: the statistics are bit-reproducible) -- saves the separate statistics pass over `out`.
 __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__restrict__ T,
                                                              const int32_t *__restrict__ pos, int64_t n, int K, int C4,
@@ -346,32 +346,6 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__res
     }
 }
 
-// one workgroup per 4 channels: 64 lanes stride over the partial blocks (two loads in flight), then a fixed-order
-// tree in LDS
-__global__ __launch_bounds__(256) void k_stats_finish(const double *__restrict__ partial, int nb, int C2,
-                                                      double *__restrict__ sums) {
-    __shared__ double red[256];
-    const int cl = threadIdx.x & 3, bl = threadIdx.x >> 2;
-    const int c = blockIdx.x * 4 + cl;
-    double s0 = 0, s1 = 0;
-    if (c < C2) {
-        int b = bl;
-        for (; b + 64 < nb; b += 128) {
-            s0 += partial[(size_t)b * C2 + c];
-            s1 += partial[(size_t)(b + 64) * C2 + c];
-        }
-        if (b < nb) s0 += partial[(size_t)b * C2 + c];
-    }
-    red[threadIdx.x] = s0 + s1;
-    __syncthreads();
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        if (bl < d) red[threadIdx.x] += red[threadIdx.x + d * 4];
-        __syncthreads();
-    }
-    if (bl == 0 && c < C2) sums[c] = red[cl];
-}
-
 extern "C" int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C) {
     // doubles of workspace needed by lidog_sconv_reduce_stats
     (void)n;
@@ -379,17 +353,20 @@ extern "C" int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C) {
 }
 
 extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C,
-                                        const float *bias, float *out, double *sums, double *partial_ws,
-                                        void *stream) {
+                                        const float *bias, float *out, double *sums, double *partial_ws, double count,
+                                        float eps, float momentum, float *mean, float *invstd, float *running_mean,
+                                        float *running_var, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconv_reduce_stats: C must be a multiple of 4, <= 1024");
+    LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_reduce_stats: finalising needs the row count");
     if (n == 0) return 0;
     int C4 = C / 4, RB = 256 / C4;
     int64_t nb = cdiv64(n, (int64_t)RB * 4);
     if (nb > 2048) nb = 2048;
     k_sconv_reduce4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, pos, n, K, C4, (const float4 *)bias,
                                                         (float4 *)out, partial_ws);
-    k_stats_finish<<<(unsigned)cdiv64(2 * C, 4), 256, 0, st>>>(partial_ws, (int)nb, 2 * C, sums);
+    BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
+    lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

@@ -14,6 +14,7 @@ Mirrors the surface of MinkowskiEngine 0.5.4 that LiDOG's models and pipelines u
 is no CPU path (tensors on the CPU raise).
 """
 import math
+import os
 import sys
 import types
 
@@ -122,6 +123,76 @@ def _side_stream(device):
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
     return _SIDE_STREAMS[key]
+
+
+class _WgradLane:
+    """Second stream of the backward pass.  A weight gradient depends only on tensors that exist when its
+    convolution's backward starts and nothing in the backward chain depends on it, so it is queued on a side
+    stream and runs next to the data-gradient chain (the chain is a sequence of dependent kernels with tails and
+    many microsecond-sized BatchNorm launches; SyncBatchNorm adds a collective per layer to it).  Only used when
+    the gradient is written straight into the optimiser's flat buffer (me._grad_out): a fresh tensor would be
+    touched by autograd on the main stream right after backward() returns it.
+    Tensors read on the side stream are kept alive until the join (also keeps autograd from accumulating into
+    them in place); the join is an engine callback at the end of the backward pass."""
+
+    # LIDOG_BACKWARD_OVERLAP=1 / 0 forces it on / off; default: on in data-parallel runs only.  On one GPU the
+    # backward chain has no collectives to wait for and the second stream buys 2.7 % (measured, bs 4) while every
+    # data-gradient kernel shares the chip with a weight gradient, which blurs per-kernel timings.
+    _env = os.environ.get("LIDOG_BACKWARD_OVERLAP", "auto")
+    enabled = {"1": True, "0": False}.get(_env)
+    _lanes = {}
+
+    @classmethod
+    def active(cls):
+        if cls.enabled is None:
+            import torch.distributed as dist
+            return dist.is_available() and dist.is_initialized()
+        return cls.enabled
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device)
+        self.keep = []
+        self.pending = False
+
+    @classmethod
+    def get(cls, device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in cls._lanes:
+            cls._lanes[key] = cls(torch.device("cuda", key))
+        return cls._lanes[key]
+
+    def fork(self, *tensors):
+        """side stream waits for everything queued on the current stream so far; returns the side stream"""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self.keep.extend(tensors)
+        if not self.pending:
+            self.pending = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+            except RuntimeError:   # not inside a backward pass: the caller joins
+                pass
+        return self.stream
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self.pending = False
+            self.keep = []
+
+
+def set_backward_overlap(on):
+    """weight gradients on a second stream (True), in line on the current stream (False), or decided per run:
+    second stream when torch.distributed is initialised (None, the default)"""
+    _WgradLane.enabled = None if on is None else bool(on)
+
+
+def wgrad_lane(device):
+    """the lane if weight gradients may still be in flight on it, else None (lidog_amd.trainer orders its
+    gradient all-reduces after it)"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    lane = _WgradLane._lanes.get(key)
+    return lane if lane is not None and lane.pending else None
 
 
 class CoordinateManager:
@@ -507,8 +578,9 @@ class _SparseConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, bias, m, swap, single_out, single_in, stats=None):
-        """`stats`: optional one-element list; when the output goes through the reduction pass, the fp64
-        BatchNorm sums of `out` are produced by that pass and returned in stats[0] (shape [2*Cout+1])."""
+        """`stats`: optional StatsRequest of the BatchNorm that follows; when the output goes through the reduction
+        pass, that pass also produces the fp64 sums of `out` (and, for a local BatchNorm, mean / invstd / running
+        statistics), returned in the request."""
         x = x.contiguous()
         W3 = W.contiguous().view(m.K, W.shape[-2], W.shape[-1])
         K, Cin, Cout = W3.shape
@@ -529,12 +601,19 @@ class _SparseConvFn(torch.autograd.Function):
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
             _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
             if stats is not None and Cout % 4 == 0 and Cout <= 1024:
-                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=x.device)
-                ws = torch.empty(_lib.load().lidog_sconv_reduce_stats_ws(n_out, Cout), dtype=torch.float64,
-                                 device=x.device)
-                call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
-                     ptr(ws))
-                stats[0] = sums
+                dev = x.device
+                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
+                ws = torch.empty(_lib.load().lidog_sconv_reduce_stats_ws(n_out, Cout), dtype=torch.float64, device=dev)
+                if stats.sync:   # the sums (and the row count behind them) still have to be all-reduced
+                    call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
+                         ptr(ws), float(n_out), 0.0, 0.0, None, None, None, None)
+                else:            # local BatchNorm: mean / invstd / running statistics finalised in the same launch
+                    stats.mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+                    stats.invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+                    call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
+                         ptr(ws), float(n_out), stats.eps, stats.momentum, ptr(stats.mean), ptr(stats.invstd),
+                         ptr(stats.running_mean), ptr(stats.running_var))
+                stats.sums = sums
             else:
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
         ctx.save_for_backward(x, W3)
@@ -557,6 +636,23 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             g_in, g_out, pos_i, n_in = m.pair_out, m.pair_in, m.pos_out, m.n_out
         gx = gW = gb = None
+        if ctx.needs_input_grad[1]:
+            # queued before the data gradient so that the side stream can start right away
+            gW = _grad_out(ctx.w_param, W3.shape)
+            items, n_items, item_off = _wgrad_items(m, Cin, Cout)
+            slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, n_items)
+
+            def wgrad(gW):
+                partial = torch.empty((max(slabs, 1), Cin, Cout), dtype=torch.float32, device=x.device)
+                call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items,
+                     ptr(item_off), K, Cin, Cout, ptr(partial), ptr(gW))
+            if gW is not None and _WgradLane.active():
+                with torch.cuda.stream(_WgradLane.get(x.device).fork(x, gout, m)):
+                    wgrad(gW)
+            else:
+                gW = gW if gW is not None else torch.empty_like(W3)
+                wgrad(gW)
+            gW = gW.view(ctx.w_shape)
         if ctx.needs_input_grad[0]:
             Wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
             call("lidog_transpose_kernel", ptr(W3), K, Cin, Cout, ptr(Wt))
@@ -569,16 +665,6 @@ class _SparseConvFn(torch.autograd.Function):
                 T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(gx))
-        if ctx.needs_input_grad[1]:
-            gW = _grad_out(ctx.w_param, W3.shape)
-            if gW is None:
-                gW = torch.empty_like(W3)
-            items, n_items, item_off = _wgrad_items(m, Cin, Cout)
-            slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, n_items)
-            partial = torch.empty((max(slabs, 1), Cin, Cout), dtype=torch.float32, device=x.device)
-            call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items, ptr(item_off),
-                 K, Cin, Cout, ptr(partial), ptr(gW))
-            gW = gW.view(ctx.w_shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(dim=0, keepdim=True)
         return gx, gW, gb, None, None, None, None, None
@@ -590,38 +676,62 @@ def _bn_ws(C, hw, dev):
     return torch.empty(n, dtype=torch.float64, device=dev) if n else None
 
 
+class StatsRequest:
+    """What a convolution needs to know to produce the statistics of the BatchNorm that follows it in the
+    epilogue of its reduction pass (conv_bn), and where it leaves them."""
+    __slots__ = ("eps", "momentum", "running_mean", "running_var", "sync", "sums", "mean", "invstd")
+
+    def __init__(self, bn, sync):
+        self.eps = float(bn.eps)
+        self.momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+        self.running_mean, self.running_var = bn.running_mean, bn.running_var
+        self.sync = sync
+        self.sums = self.mean = self.invstd = None
+
+
 class _BatchNormFn(torch.autograd.Function):
     """BatchNorm over rows ([n,C], hw=1) or NCHW images (hw=H*W), optional fused residual add and ReLU.
     `group`: torch.distributed process group for SyncBatchNorm statistics (None = local).
-    `sums`: optional fp64 [2C+1] buffer whose first 2C entries already hold (sum x, sum x^2), produced by the
-    epilogue of the convolution that made x (saves one pass over x)."""
+    `pre`: optional (sums, mean, invstd) from the epilogue of the convolution that made x (saves one pass over
+    x): fp64 sums [2C+1] = (sum x, sum x^2, rows); mean / invstd None when they still have to be derived
+    (SyncBatchNorm: after the all-reduce).
+    SyncBatchNorm costs ONE collective per direction and no extra kernel: the reductions leave the local row
+    count behind their sums, the all-reduce turns both into global figures, the consumers read the count from
+    the device."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, hw, relu, residual, group,
-                sums):
+                pre):
         x = x.contiguous()
         if hw == 1:
             n, C = x.shape
         else:
             n, C = x.shape[0], x.shape[1]
-        count = float(n * hw)
+        rows = float(n * hw)
+        count = rows
         dev = x.device
-        count_t = None
         if training:
+            sums, mean, invstd = pre if pre is not None else (None, None, None)
+            sync = group is not None
             if sums is None:
                 sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-                call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)))
-            if group is not None:
-                # (sum x, sum x^2, rows) summed over the ranks in ONE message; the count stays on the device
+                if sync:
+                    call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)), rows, 0.0, 0.0,
+                         None, None, None, None)
+                else:
+                    mean = torch.empty(C, dtype=torch.float32, device=dev)
+                    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                    call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)), rows, float(eps),
+                         float(momentum), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var))
+            if sync:
                 import torch.distributed as dist
-                sums[2 * C] = count
-                dist.all_reduce(sums, group=group)
-                count_t = sums[2 * C:].clone()
-                count = -1.0
-            mean = torch.empty(C, dtype=torch.float32, device=dev)
-            invstd = torch.empty(C, dtype=torch.float32, device=dev)
-            call("lidog_bn_finalize", ptr(sums), count, C, float(eps), float(momentum), ptr(mean), ptr(invstd),
-                 ptr(running_mean), ptr(running_var))
+                dist.all_reduce(sums, group=group)   # (sum x, sum x^2, rows) in ONE message
+                count = -1.0                          # consumers read the global count from sums[2C]
+            if mean is None:
+                mean = torch.empty(C, dtype=torch.float32, device=dev)
+                invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                call("lidog_bn_finalize", ptr(sums), count, C, float(eps), float(momentum), ptr(mean), ptr(invstd),
+                     ptr(running_mean), ptr(running_var))
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
@@ -629,42 +739,37 @@ class _BatchNormFn(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         call("lidog_bn_apply", ptr(x), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(res),
              1 if relu else 0, ptr(y))
-        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None, count_t)
-        ctx.cfg = (n, C, hw, count, training, residual is not None, group)
+        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+        ctx.cfg = (n, C, hw, rows, training, residual is not None, group)
         ctx.params = (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, mean, invstd, y, count_t = ctx.saved_tensors
-        n, C, hw, count, training, has_res, group = ctx.cfg
+        x, weight, mean, invstd, y = ctx.saved_tensors
+        n, C, hw, rows, training, has_res, group = ctx.cfg
         dy = dy.contiguous()
         dev = x.device
         sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-        call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums),
-             ptr(_bn_ws(C, hw, dev)))
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
-        # parameter gradients come from the LOCAL sums (DDP averages them afterwards); they are written
-        # straight into the optimiser's flat gradient buffer when there is one
+        # parameter gradients are the LOCAL sums (DDP averages them afterwards), written by the last kernel of the
+        # reduction straight into the optimiser's flat gradient buffer when there is one
         dw = _grad_out(ctx.params[0], (C,))
         db = _grad_out(ctx.params[1], (C,))
         dw = dw if dw is not None else torch.empty(C, dtype=torch.float32, device=dev)
         db = db if db is not None else torch.empty(C, dtype=torch.float32, device=dev)
-        if training and group is None:
-            call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
-                 ptr(sums), count, ptr(dx), ptr(dres), ptr(dw), ptr(db))
-        else:
-            db.copy_(sums[:C])
-            dw.copy_(sums[C:2 * C])
-            if not training:
-                sums.zero_()  # running statistics are constants: dx = dy' * w * invstd
-            else:
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=group)
-                sums[2 * C:] = count_t
-            call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
-                 ptr(sums), count, ptr(dx), ptr(dres), None, None)
+        call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums),
+             ptr(_bn_ws(C, hw, dev)), rows, ptr(dw), ptr(db))
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        count = rows
+        if not training:
+            sums.zero_()  # running statistics are constants: dx = dy' * w * invstd
+        elif group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group)   # (sum dy', sum dy' xhat, rows)
+            count = -1.0
+        call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
+             ptr(sums), count, ptr(dx), ptr(dres), None, None)
         return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
 
 
@@ -685,8 +790,9 @@ def _count_batch(bn):
         bn.register_load_state_dict_pre_hook(lambda module, *_: setattr(module, "_nbt_pending", 0))
 
 
-def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, sums=None):
-    """functional entry used by the modules below and by lidog_amd.bev"""
+def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, stats=None):
+    """functional entry used by the modules below and by lidog_amd.bev; `stats`: the StatsRequest a convolution
+    has filled (conv_bn), or None"""
     training = bn.training or not bn.track_running_stats
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if bn.momentum is None:  # cumulative average reads the counter: keep it exact on the device
@@ -694,8 +800,9 @@ def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, sums=None):
         else:
             _count_batch(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
+    pre = (stats.sums, stats.mean, stats.invstd) if (training and stats is not None and stats.sums is not None) else None
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
-                              hw, relu, residual, group, sums if training else None)
+                              hw, relu, residual, group, pre)
 
 
 # ------------------------------------------------------------------ modules
@@ -764,9 +871,9 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
 
-    def forward(self, x, relu=False, residual=None, sums=None):
+    def forward(self, x, relu=False, residual=None, stats=None):
         res = residual.F if residual is not None else None
-        return x._like(batch_norm(x.F, self.bn, 1, relu, res, self._sync_group(), sums))
+        return x._like(batch_norm(x.F, self.bn, 1, relu, res, self._sync_group(), stats))
 
     def _sync_group(self):
         return None
@@ -781,9 +888,12 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.process_group = process_group
 
+    single_rank = False   # test hook: run the collectives even in a one-rank process group
+
     def _sync_group(self):
         import torch.distributed as dist
-        if not (self.training and dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (self.training and dist.is_available() and dist.is_initialized()) or \
+                (dist.get_world_size() == 1 and not MinkowskiSyncBatchNorm.single_rank):
             return None
         return self.process_group if self.process_group is not None else dist.group.WORLD
 
@@ -815,9 +925,12 @@ class MinkowskiReLU(nn.Module):
 def conv_bn(conv, bn_module, x, relu=False, residual=None):
     """convolution + BatchNorm (+ residual add + ReLU): the BN statistics come out of the convolution's
     reduction pass, the affine/add/ReLU is one fused elementwise pass"""
-    holder = [None] if (bn_module.bn.training or not bn_module.bn.track_running_stats) else None
-    y = conv(x, stats=holder)
-    return bn_module(y, relu=relu, residual=residual, sums=holder[0] if holder is not None else None)
+    bn = bn_module.bn
+    req = None
+    if bn.training or not bn.track_running_stats:
+        req = StatsRequest(bn, bn_module._sync_group() is not None)
+    y = conv(x, stats=req)
+    return bn_module(y, relu=relu, residual=residual, stats=req)
 
 
 def bn_relu(bn_module, x):

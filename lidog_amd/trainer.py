@@ -72,15 +72,19 @@ class GradientBuckets:
     contiguous slices walked from the END of the buffer.  xGMI is point-to-point (7 links per GPU):
     a few large messages (default 32 MiB) keep every link busy without paying per-message latency."""
 
+    single_rank = False   # test hook: bucket and all-reduce even in a one-rank process group
+
     def __init__(self, flat, group=None, bucket_bytes=32 << 20):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (self.single_rank and dist.is_initialized())
         self.handles = []
+        self.deferred = []
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         self.bucket_of = {}
         self.pending0 = []
         self.slices = []
-        if self.world == 1:
+        if not self.active:
             return
         cur_lo = cur_hi = flat.total
         count = 0
@@ -114,17 +118,31 @@ class GradientBuckets:
         b = self.bucket_of[id(p)]
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            lo, hi = self.slices[b]
-            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+            self._reduce(b)
+
+    def _reduce(self, b):
+        lo, hi = self.slices[b]
+        buf = self.flat.grad[lo:hi]
+        if buf.is_cuda and ME._WgradLane.active():
+            # Weight gradients of this bucket may still be running on the second stream of the backward pass, and
+            # a collective queued now would sit in RCCL's stream in front of every later SyncBatchNorm all-reduce
+            # until they are done, stalling the data-gradient chain behind the weight gradients.  The bucket is
+            # reduced after the join instead (finish()); 155 MB over xGMI is ~1 ms at 8 GPUs.
+            self.deferred.append(b)
+            return
+        self.handles.append(dist.all_reduce(buf, group=self.group, async_op=True))
 
     def finish(self):
         """wait for every bucket; buckets whose hooks did not all fire (unused parameters) are reduced now"""
-        if self.world == 1:
+        if not self.active:
             return
         for b, left in enumerate(self.pending):
             if left > 0:
-                lo, hi = self.slices[b]
-                self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+                self._reduce(b)
+        for b in self.deferred:   # the engine callback of the second stream has joined it by now
+            lo, hi = self.slices[b]
+            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], group=self.group, async_op=True))
+        self.deferred = []
         for h in self.handles:
             h.wait()
         self.handles = []
@@ -148,6 +166,9 @@ class FlatAdam:
         self.flat.zero_grad()
 
     def step(self):
+        lane = ME.wgrad_lane(self.flat.grad.device) if self.flat.grad.is_cuda else None
+        if lane is not None:   # normally joined already by the engine callback at the end of backward()
+            lane.join()
         self.strays = self.flat.gather_strays()
         self.buckets.finish()
         self.steps += 1
@@ -251,7 +272,7 @@ class SourceStep(_CoordinatePrefetch):
 def setup_data_parallel(model):
     """train_lidog.py:227-231: SyncBatchNorm conversion of the sparse BNs when world_size > 1 (the two
     BatchNorm2d of Encoder2D stay per-rank, as in the reference)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or ME.MinkowskiSyncBatchNorm.single_rank):
         model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
     return model
 

@@ -78,3 +78,26 @@ def test_syncbn_and_ddp_two_processes_one_gpu():
         p.join(60)
         assert p.exitcode == 0
     assert got == {0: True, 1: True}
+
+
+def _bench_line(extra_env):
+    import json
+    import subprocess
+    env = dict(os.environ, **extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_rank_rccl_runs_every_data_parallel_path():
+    """The collectives of the N > 1 runs against the real RCCL library (backend "nccl") in a ONE-rank process
+    group: fp64 SyncBN statistics all-reduces (forward and backward of the 62 sparse BNs), bucketed asynchronous
+    gradient all-reduces issued from the second backward stream, barrier, destroy.  With one rank every
+    all-reduce is the identity, so the step must reproduce the plain single-GPU step."""
+    port = 29700 + os.getpid() % 2000
+    plain = _bench_line({"LIDOG_BACKWARD_OVERLAP": "0"})
+    dp = _bench_line({"LIDOG_BENCH_SINGLE_RANK_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    assert dp["config"]["parallelism"] == "dp1+syncbn" and plain["config"]["parallelism"] == "dp1"
+    assert abs(dp["loss"] - plain["loss"]) <= 2e-5 * abs(plain["loss"]), (dp["loss"], plain["loss"])

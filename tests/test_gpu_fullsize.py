@@ -46,6 +46,7 @@ def test_maps_at_120k_points():
 
 def test_conv_linearity_adjointness_and_reproducibility_at_120k_points():
     import lidog_amd.me as ME
+    torch.manual_seed(0)   # the kernel initialisation draws from the global generator
     st, _ = _tensor("kitti120k", [2])
     cm, n = st.coordinate_manager, st.F.shape[0]
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -60,9 +61,12 @@ def test_conv_linearity_adjointness_and_reproducibility_at_120k_points():
     assert (lin - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
     out.backward(gy)
     # <conv(x), g> == <x, conv^T(g)>  (the data gradient is the adjoint)   and   == <W, dW>
+    # the inner product is a sum of ~7 M signed terms that cancel almost completely, so the tolerance is
+    # relative to the sum of their magnitudes (fp32 rounding of each term), not to the small total
     lhs = (out.detach().double() * gy.double()).sum()
-    assert abs(float(lhs - (x.detach().double() * x.grad.double()).sum())) <= 1e-5 * abs(float(lhs))
-    assert abs(float(lhs - (conv.kernel.detach().double() * conv.kernel.grad.double()).sum())) <= 1e-4 * abs(float(lhs))
+    scale = float((out.detach().double().abs() * gy.double().abs()).sum())
+    assert abs(float(lhs - (x.detach().double() * x.grad.double()).sum())) <= 1e-6 * scale
+    assert abs(float(lhs - (conv.kernel.detach().double() * conv.kernel.grad.double()).sum())) <= 1e-6 * scale
     # no atomics in the convolution: forward, data gradient and weight gradient are bit-reproducible
     gx1, gw1 = x.grad.clone(), conv.kernel.grad.clone()
     x.grad, conv.kernel.grad = None, None
