@@ -188,6 +188,27 @@ int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, int32_t Cin, 
                        int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, float *gw, float *gbias,
                        float *ws, int64_t ws_floats, void *stream);
 
+/* Conv2d(k3,s2,p1,bias=False) over a structurally sparse input (the image made by sparse2super: ~95 % empty cells).
+ * support [B,Cin,H,W] int32: >= 0 where the cell can be non-zero / its gradient is needed (the arg-max source map
+ * of lidog_bev_pool_fwd), < 0 where x is exactly 0 and its gradient is never read.
+ * lidog_conv2d_support turns it into per-tile lists of active input channels (act: lidog_conv2d_support_ws int32);
+ * fwd_sparse = lidog_conv2d_fwd restricted to them (bit-identical result); dgrad_sparse writes gx ONLY for the
+ * active channels of every 128-pixel tile (a superset of the cells with support >= 0), the rest of gx is untouched;
+ * wgrad_sparse = lidog_conv2d_wgrad visiting, for every group of 3 input channels, only the pixel tiles in which
+ * one of them is active (equal up to the order of the split sums).
+ * ws: Cin*9*Cout floats (transposed / parity-class repacked weights); wgrad: lidog_conv2d_wgrad_sparse_ws floats
+ * (one slab of Cout*Cin*9 per work item of a channel group).  Cin <= 128, Cout % 128 == 0. */
+int64_t lidog_conv2d_support_ws(int32_t B, int32_t Cin, int32_t H, int32_t W);
+int lidog_conv2d_support(const int32_t *support, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t *act,
+                         void *stream);
+int lidog_conv2d_fwd_sparse(const float *x, const float *w, const int32_t *act, int32_t B, int32_t Cin, int32_t H,
+                            int32_t W, int32_t Cout, float *y, float *ws, void *stream);
+int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const int32_t *act, int32_t B, int32_t Cin, int32_t H,
+                              int32_t W, int32_t Cout, float *gx, float *ws, void *stream);
+int64_t lidog_conv2d_wgrad_sparse_ws(int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout); /* floats of ws */
+int lidog_conv2d_wgrad_sparse(const float *x, const float *gy, const int32_t *act, int32_t B, int32_t Cin, int32_t H,
+                              int32_t W, int32_t Cout, float *gw, float *ws, int64_t ws_floats, void *stream);
+
 /* ------------------------------------------------------------------ DICE losses
  * utils/losses/losses.py:56-97 (DICELoss: soft = 0) and :100-187 (SoftDICELoss: soft = 1, label smoothing eps,
  * powerize, present-class mask), as called by trainer_lighting_2d.py:172-190.  logits [n, C] float32 (C in

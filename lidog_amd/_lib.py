@@ -7,7 +7,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "_C", "liblidog_amd.so")
+# LIDOG_SO: another build of the same library (kernel A/B runs); there is still no fallback behind it
+SO_PATH = os.environ.get("LIDOG_SO") or os.path.join(_HERE, "_C", "liblidog_amd.so")
 
 _i32, _i64, _p, _f, _d = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_float, ctypes.c_double
 
@@ -44,6 +45,12 @@ SIGNATURES = {
     "lidog_conv2d_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_conv2d_dgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_conv2d_wgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
+    "lidog_conv2d_support_ws": [_i32, _i32, _i32, _i32],
+    "lidog_conv2d_support": [_p, _i32, _i32, _i32, _i32, _p, _p],
+    "lidog_conv2d_fwd_sparse": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_conv2d_dgrad_sparse": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_conv2d_wgrad_sparse_ws": [_i32, _i32, _i32, _i32, _i32],
+    "lidog_conv2d_wgrad_sparse": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _p],
     "lidog_voxel_floor": [_p, _i64, _f, _f, _f, _i32, _p, _p],
     "lidog_label_vote": [_p, _p, _p, _i64, _i64, _i32, _p, _p],
     "lidog_bev_label_raster": [_p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
@@ -53,7 +60,7 @@ SIGNATURES = {
     "lidog_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i32, _f, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
-             "lidog_dice_ws": _i64}
+             "lidog_dice_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}
 
 _lib = None
 

@@ -1,0 +1,25 @@
+// Shared by conv2d.hip (dense implicit-GEMM kernels) and conv2d_sparse.hip (structurally sparse input).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define IG_T 128
+#define IG_LD 132
+
+struct IgParams {
+    const float *A;   // FWD: W [Cout][Cin*9]; DGRAD: Wd class slab [Cin][Cout*nt]; WGRAD: gY
+    const float *Bm;  // FWD/WGRAD: X; DGRAD: gY
+    float *D;         // FWD: Y; DGRAD: gX; WGRAD: partial slab [split][Cout][Cin*9]
+    int Bn, Cin, H, W, Cout, Ho, Wo;
+    int Mi, Nj, Kd;   // GEMM extents
+    // DGRAD class description
+    int py, px, nky, nkx, Hc, Wc;
+    int ky0, kystep, kx0, kxstep;
+    // WGRAD split
+    int k_chunk;
+};
+
+enum { IG_FWD = 0, IG_DGRAD = 1, IG_WGRAD = 2 };
+
+#define C2_KB 32  // reduction depth of one LDS stage (FWD / DGRAD)

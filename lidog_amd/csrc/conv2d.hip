@@ -12,25 +12,7 @@
 //   WGRAD  i = co, k = (b,yo,xo),  j = (ci,ky,kx)   A = gY[co][k]          B = im2col(X)^T, split over k
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define IG_T 128
-#define IG_LD 132
-
-struct IgParams {
-    const float *A;   // FWD: W [Cout][Cin*9]; DGRAD: Wd class slab [Cin][Cout*nt]; WGRAD: gY
-    const float *Bm;  // FWD/WGRAD: X; DGRAD: gY
-    float *D;         // FWD: Y; DGRAD: gX; WGRAD: partial slab [split][Cout][Cin*9]
-    int Bn, Cin, H, W, Cout, Ho, Wo;
-    int Mi, Nj, Kd;   // GEMM extents
-    // DGRAD class description
-    int py, px, nky, nkx, Hc, Wc;
-    int ky0, kystep, kx0, kxstep;
-    // WGRAD split
-    int k_chunk;
-};
-
-enum { IG_FWD = 0, IG_DGRAD = 1, IG_WGRAD = 2 };
+#include "conv2d.h"
 
 // ------------------------------------------------------------------ WGRAD
 // D[co][(ci,ky,kx)] = sum over pixels k = (b,yo,xo) of gY[co][k] * X[ci][2yo-1+ky][2xo-1+kx], split over k.
@@ -186,7 +168,6 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(IgParams p) {
 //  - the LDS operand reads of MFMA step k2+1 are issued before the MFMAs of step k2 (sched_barrier).
 // WM x (4/WM) waves, each TI x TJ MFMA tiles: 128 x 128 (WM=2,TI=2,TJ=2) or 96 x 128 (WM=1,TI=3,TJ=1; the
 // data gradient of a 96-channel input would waste a quarter of a 128-row tile).
-#define C2_KB 32
 template <int MODE, int WM, int TI, int TJ>
 __global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
     constexpr int TMR = WM * TI * 32;              // tile rows (i)

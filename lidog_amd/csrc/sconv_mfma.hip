@@ -237,7 +237,9 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
     __shared__ __attribute__((aligned(16))) float Gs[MW_R * TN];
     // work item = (offset k, pair range [p0, p1)): ranges are cut to equal length on the host, so the offsets
     // with many pairs (the centre offset owns one pair per voxel) get proportionally more workgroups
-    const int item = blockIdx.x;
+    // row 3 of the item table = launch order: workgroup x runs item order[x] (me.py:_wgrad_items_host puts items that
+    // read the same feature rows next to each other in time and on the same XCD)
+    const int item = items[3 * n_items + blockIdx.x];
     const int tiles_n = Cout / TN;
     const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

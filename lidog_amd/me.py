@@ -541,8 +541,17 @@ def _wgrad_chunk(P, Cin, Cout):
     return (chunk + 31) // 32 * 32
 
 
+_WGRAD_ORDER = int(os.environ.get("LIDOG_WGRAD_ORDER", "2"))
+_WGRAD_GROUP = int(os.environ.get("LIDOG_WGRAD_GROUP", "32"))
+
+
 def _wgrad_items_host(k_off_host, chunk):
-    """(items int32 [3, n] = (k, first pair, end pair), n, item_off int32 [K+1]) as numpy arrays"""
+    """(items int32 [4, n] = (k, first pair, end pair, launch order), n, item_off int32 [K+1]) as numpy arrays.
+    Rows 0-2 are ordered by k (the partial slots of one offset are contiguous); row 3 says which item workgroup x
+    runs: pairs are sorted by output row inside an offset, so the items at the same relative position of their
+    offsets read (nearly) the same feature and gradient rows -- they are launched together, and in groups that
+    land on the same XCD (workgroups go to the 8 XCDs round-robin), so that a row fetched for one offset is still
+    in that XCD's L2 for the others."""
     k_off = np.asarray(k_off_host, dtype=np.int64)
     cnt = np.diff(k_off)
     n_k = (cnt + chunk - 1) // chunk
@@ -552,7 +561,15 @@ def _wgrad_items_host(k_off_host, chunk):
     within = np.arange(total, dtype=np.int64) - first
     p0 = k_off[item_k] + within * chunk
     p1 = np.minimum(p0 + chunk, k_off[item_k + 1])
-    return (np.stack([item_k, p0, p1]).astype(np.int32), total,
+    order = np.arange(total, dtype=np.int64)
+    if _WGRAD_ORDER >= 1 and total:
+        order = np.argsort((within + 0.5) / n_k[item_k], kind="stable")
+        if _WGRAD_ORDER >= 2:
+            i = np.arange(total, dtype=np.int64)
+            g, j = i // _WGRAD_GROUP, i % _WGRAD_GROUP
+            launch_id = 8 * ((g // 8) * _WGRAD_GROUP + j) + g % 8     # position in the launch sequence
+            order = order[np.argsort(launch_id, kind="stable")]
+    return (np.stack([item_k, p0, p1, order]).astype(np.int32), total,
             np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32))
 
 
