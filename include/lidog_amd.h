@@ -164,11 +164,15 @@ int lidog_bev_winner(const int32_t *coords, int64_t n, const int32_t *lut_x, con
                      int32_t lut_n, int32_t H, int32_t W, int32_t *winner /*[B,H,W], pre-filled -1*/,
                      int32_t *pixel /*[n] linear b*H*W+py*W+px or -1*/, void *stream);
 /* winner/pixel/n: as produced by lidog_bev_winner for the same rows (only windows that contain a cell of an
- * occupied pixel are computed; the rest of out/argsrc is filled with 0 / -1). */
+ * occupied pixel are computed; the rest of out/argsrc is filled with 0 / -1).
+ * rowbits (may be NULL): uint64 [B*C*Ho][ceil(Wo/64)], bit x of row (b,c,yo) set for every computed window: the
+ * structural support of `out` (a superset of argsrc >= 0) in the form lidog_conv2d_support keeps at the start of
+ * its `act` buffer -- pass that buffer here and call lidog_conv2d_support(NULL, ...). */
 int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, const int32_t *pixel, int64_t n,
                        int32_t B, int32_t H, int32_t W, int32_t pk, int32_t ps, int32_t pp, int32_t Ho, int32_t Wo,
                        float *out /*[B,C,Ho,Wo]*/,
-                       int32_t *argsrc /*[B,C,Ho,Wo] row*C+c of the arg-max cell or -1*/, void *stream);
+                       int32_t *argsrc /*[B,C,Ho,Wo] row*C+c of the arg-max cell or -1*/, uint64_t *rowbits,
+                       void *stream);
 int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems, const int32_t *winner,
                        const int32_t *pixel, int64_t n, int32_t C, float *gcell /*[n,C] zeroed scratch*/,
                        float *gfeats /*[n,C]*/, void *stream);
@@ -191,7 +195,8 @@ int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, int32_t Cin, 
 /* Conv2d(k3,s2,p1,bias=False) over a structurally sparse input (the image made by sparse2super: ~95 % empty cells).
  * support [B,Cin,H,W] int32: >= 0 where the cell can be non-zero / its gradient is needed (the arg-max source map
  * of lidog_bev_pool_fwd), < 0 where x is exactly 0 and its gradient is never read.
- * lidog_conv2d_support turns it into per-tile lists of active input channels (act: lidog_conv2d_support_ws int32);
+ * lidog_conv2d_support turns it into per-tile lists of active input channels (act: lidog_conv2d_support_ws int32;
+ * support == NULL: the row bitmasks at the start of act were already written by lidog_bev_pool_fwd);
  * fwd_sparse = lidog_conv2d_fwd restricted to them (bit-identical result); dgrad_sparse writes gx ONLY for the
  * active channels of every 128-pixel tile (a superset of the cells with support >= 0), the rest of gx is untouched;
  * wgrad_sparse = lidog_conv2d_wgrad visiting, for every group of 3 input channels, only the pixel tiles in which

@@ -40,7 +40,7 @@ SIGNATURES = {
     "lidog_relu_bwd": [_p, _p, _i64, _p, _p],
     "lidog_add": [_p, _p, _i64, _p, _p],
     "lidog_bev_winner": [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
-    "lidog_bev_pool_fwd": [_p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_bev_pool_fwd": [_p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
     "lidog_bev_pool_bwd": [_p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p],
     "lidog_conv2d_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_conv2d_dgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void k_bev_pool_fwd_sparse(const float *__rest
                                                              const int32_t *__restrict__ winner,
                                                              const int32_t *__restrict__ pixel, int64_t n,
                                                              PoolGeom g, float *__restrict__ out,
-                                                             int32_t *__restrict__ argsrc) {
+                                                             int32_t *__restrict__ argsrc,
+                                                             unsigned long long *__restrict__ rowbits, int words) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
@@ -165,6 +166,17 @@ __global__ __launch_bounds__(256) void k_bev_pool_fwd_sparse(const float *__rest
         if (xo_hi > g.Wo - 1) xo_hi = g.Wo - 1;
         const int nx = xo_hi - xo_lo + 1, ny = yo_hi - yo_lo + 1;
         if (nx > 0 && ny > 0) {
+            if (rowbits && lane < ny) {
+                // structural support of the image for the convolution that reads it (conv2d_sparse.hip): one bit per
+                // computed window, row (b, cp, yo) = words of 64 columns; lane l marks row yo_lo + l
+                unsigned long long *rw = rowbits + (((size_t)b * g.C + cp) * g.Ho + (yo_lo + lane)) * words;
+                for (int w = xo_lo >> 6; w <= (xo_hi >> 6); ++w) {
+                    unsigned long long m = ~0ull;
+                    if (w == (xo_lo >> 6)) m &= ~0ull << (xo_lo & 63);
+                    if (w == (xo_hi >> 6)) m &= ~0ull >> (63 - (xo_hi & 63));
+                    atomicOr(&rw[w], m);
+                }
+            }
             float *o = out + ((size_t)b * g.C + cp) * ((size_t)g.Ho * g.Wo);
             int32_t *a = argsrc + ((size_t)b * g.C + cp) * ((size_t)g.Ho * g.Wo);
             for (int yo = yo_lo; yo <= yo_hi; ++yo)
@@ -183,7 +195,8 @@ __global__ __launch_bounds__(256) void k_bev_pool_fwd_sparse(const float *__rest
 
 extern "C" int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, const int32_t *pixel,
                                   int64_t n, int32_t B, int32_t H, int32_t W, int32_t pk, int32_t ps, int32_t pp,
-                                  int32_t Ho, int32_t Wo, float *out, int32_t *argsrc, void *stream) {
+                                  int32_t Ho, int32_t Wo, float *out, int32_t *argsrc, uint64_t *rowbits,
+                                  void *stream) {
     int64_t total = (int64_t)B * C * Ho * Wo;
     if (total == 0) return 0;
     LIDOG_REQUIRE((int64_t)H * W * C < ((int64_t)1 << 31), "bev_pool_fwd: C*H*W must stay below 2^31");
@@ -196,13 +209,18 @@ extern "C" int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *
     // windows without an occupied pixel: max over zeros = 0, no source cell
     if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return 1;
     if (hipMemsetAsync(argsrc, 0xff, sizeof(int32_t) * (size_t)total, st) != hipSuccess) return 1;
+    const int words = (Wo + 63) / 64;
+    if (rowbits && hipMemsetAsync(rowbits, 0, sizeof(uint64_t) * (size_t)B * C * Ho * words, st) != hipSuccess) return 1;
     if (n == 0) return 0;
+    LIDOG_REQUIRE(rowbits == nullptr || pk + ps <= 64, "bev_pool_fwd: row bitmasks need pool kernel + stride <= 64");
     PoolGeom g;
     g.C = C; g.H = H; g.W = W; g.pk = pk; g.ps = ps; g.pp = pp; g.Ho = Ho; g.Wo = Wo;
     g.w_div_c = W / C; g.w_mod_c = W % C;
     g.c_magic = (((uint64_t)1 << 40) + (uint64_t)C - 1) / (uint64_t)C;
     const unsigned grid = (unsigned)cdiv64(n, 4);
-#define BEV_POOL_LAUNCH(PK) k_bev_pool_fwd_sparse<PK><<<grid, 256, 0, st>>>(feats, winner, pixel, n, g, out, argsrc)
+#define BEV_POOL_LAUNCH(PK)                                                                                     \
+    k_bev_pool_fwd_sparse<PK><<<grid, 256, 0, st>>>(feats, winner, pixel, n, g, out, argsrc,                    \
+                                                    reinterpret_cast<unsigned long long *>(rowbits), words)
     if (pk <= 3) BEV_POOL_LAUNCH(3);
     else if (pk <= 5) BEV_POOL_LAUNCH(5);
     else BEV_POOL_LAUNCH(8);

@@ -160,7 +160,8 @@ extern "C" int lidog_conv2d_support(const int32_t *support, int32_t B, int32_t C
     ActLayout L = act_layout(B, Cin, H, W);
     uint64_t *bits = reinterpret_cast<uint64_t *>(act + L.bits_off);
     int64_t rows = (int64_t)B * Cin * H;
-    k_support_rowbits<<<(unsigned)cdiv64(rows, 4), 256, 0, st>>>(support, rows, W, L.words, bits);
+    if (support)  // NULL: lidog_bev_pool_fwd has already written the row bitmasks
+        k_support_rowbits<<<(unsigned)cdiv64(rows, 4), 256, 0, st>>>(support, rows, W, L.words, bits);
     ListGeom g;
     g.C = Cin; g.H = H; g.W = W;
     g.Hc = out_dim2(H); g.Wc = out_dim2(W); g.Nj = B * g.Hc * g.Wc;

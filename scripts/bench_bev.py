@@ -35,7 +35,7 @@ def t(fn, reps=5):
     fn(); torch.cuda.synchronize(); e0.record()
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / reps
-print("pool kernel        ", t(lambda: call("lidog_bev_pool_fwd", ptr(feats), C, ptr(winner), ptr(pixel), n, 4, H, W, 5, 3, 1, Ho, Wo, ptr(out), ptr(arg))), "ms")
-print("pool kernel (empty)", t(lambda: call("lidog_bev_pool_fwd", ptr(feats), C, ptr(empty), ptr(pixel), n, 4, H, W, 5, 3, 1, Ho, Wo, ptr(out), ptr(arg))), "ms")
+print("pool kernel        ", t(lambda: call("lidog_bev_pool_fwd", ptr(feats), C, ptr(winner), ptr(pixel), n, 4, H, W, 5, 3, 1, Ho, Wo, ptr(out), ptr(arg), None)), "ms")
+print("pool kernel (empty)", t(lambda: call("lidog_bev_pool_fwd", ptr(feats), C, ptr(empty), ptr(pixel), n, 4, H, W, 5, 3, 1, Ho, Wo, ptr(out), ptr(arg), None)), "ms")
 print("fill out+arg       ", t(lambda: (out.fill_(0), arg.fill_(-1))), "ms")
 print("occupied pixels", int((winner >= 0).sum()), "of", winner.numel())
