@@ -153,6 +153,9 @@ int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, in
 int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                        const float *mean, const float *invstd, const float *w, const double *sums, double count,
                        float *dx, float *dres, float *dw, float *db, void *stream);
+/* out[c] = sum over the n rows of x[., c] for a narrow matrix (C <= 16; the classifier's bias gradient); ws: 512*C
+ * doubles */
+int lidog_colsum(const float *x, int64_t n, int32_t C, float *out, double *ws, void *stream);
 int lidog_relu_fwd(const float *x, int64_t n, float *y, void *stream);
 int lidog_relu_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream);
 int lidog_add(const float *a, const float *b, int64_t n, float *out, void *stream);

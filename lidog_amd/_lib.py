@@ -36,6 +36,7 @@ SIGNATURES = {
     "lidog_bn_apply": [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p],
     "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
+    "lidog_colsum": [_p, _i64, _i32, _p, _p, _p],
     "lidog_relu_fwd": [_p, _i64, _p, _p],
     "lidog_relu_bwd": [_p, _p, _i64, _p, _p],
     "lidog_add": [_p, _p, _i64, _p, _p],

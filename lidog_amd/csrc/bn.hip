@@ -456,6 +456,55 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
     return 0;
 }
 
+// column sums of a narrow [n, C] matrix (C <= 16): the bias gradient of the classifier (96 -> 7).  Every workgroup
+// sums a contiguous slab of rows in double, the slabs are added in order by the second kernel (no atomics).
+#define COLSUM_BLOCKS 512
+__global__ __launch_bounds__(256) void k_colsum_narrow(const float *__restrict__ x, int64_t n, int C,
+                                                       double *__restrict__ partial) {
+    __shared__ double red[4][16];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float *row = x + r * C;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < C) acc[j] += (double)row[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double v = acc[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < C)
+        partial[(size_t)blockIdx.x * C + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void k_colsum_finish(const double *__restrict__ partial, int nb, int C, float *__restrict__ out) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * C + c];
+    out[c] = (float)s;
+}
+
+extern "C" int lidog_colsum(const float *x, int64_t n, int32_t C, float *out, double *ws, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(C >= 1 && C <= 16, "colsum: 1 <= C <= 16");
+    LIDOG_REQUIRE(ws != nullptr, "colsum: needs a workspace of 512 * C doubles");
+    if (n == 0) return hipMemsetAsync(out, 0, sizeof(float) * C, st) == hipSuccess ? 0 : 1;
+    int nb = (int)(cdiv64(n, 1024) < COLSUM_BLOCKS ? cdiv64(n, 1024) : COLSUM_BLOCKS);
+    k_colsum_narrow<<<nb, 256, 0, st>>>(x, n, C, ws);
+    k_colsum_finish<<<1, 64, 0, st>>>(ws, nb, C, out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void k_relu_fwd(const float *__restrict__ x, int64_t n, float *__restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         y[i] = fmaxf(x[i], 0.f);

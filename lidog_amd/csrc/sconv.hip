@@ -558,12 +558,25 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cout8(const float *__restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (r < RL) {
-        for (int64_t p = p0 + r; p < p1; p += RL) {
-            float a = A[(size_t)pa[p] * Cin + ci];
-            const float *g = G + (size_t)pg[p] * Cout;
+        // four pairs per round, all their (dependent) index -> row loads in flight together; pairs past the end are
+        // clamped to the last one and contribute a * 0
+        for (int64_t p = p0 + r; p < p1; p += 4 * RL) {
+            float a[4], gv[4][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < Cout) acc[j] = __builtin_fmaf(a, g[j], acc[j]);
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pu = p + u * RL;
+                const int64_t pc = pu < p1 ? pu : p1 - 1;
+                a[u] = A[(size_t)pa[pc] * Cin + ci];
+                const float *g = G + (size_t)pg[pc] * Cout;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[u][j] = (j < Cout) ? g[j] : 0.f;
+                if (pu >= p1) a[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < Cout) acc[j] = __builtin_fmaf(a[u], gv[u][j], acc[j]);
         }
     }
 #pragma unroll

@@ -635,7 +635,7 @@ class _SparseConvFn(torch.autograd.Function):
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
         ctx.save_for_backward(x, W3)
         ctx.m, ctx.swap, ctx.single_in, ctx.has_bias, ctx.w_shape = m, swap, single_in, bias is not None, W.shape
-        ctx.w_param = W
+        ctx.w_param, ctx.b_param = W, bias
         return out
 
     @staticmethod
@@ -683,7 +683,13 @@ class _SparseConvFn(torch.autograd.Function):
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(gx))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gout.sum(dim=0, keepdim=True)
+            if Cout <= 16:
+                gb = _grad_out(ctx.b_param, (1, Cout))
+                gb = gb if gb is not None else torch.empty((1, Cout), dtype=torch.float32, device=x.device)
+                ws = torch.empty(512 * Cout, dtype=torch.float64, device=x.device)
+                call("lidog_colsum", ptr(gout), gout.shape[0], Cout, ptr(gb), ptr(ws))
+            else:
+                gb = gout.sum(dim=0, keepdim=True)
         return gx, gW, gb, None, None, None, None, None
 
 
