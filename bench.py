@@ -179,7 +179,20 @@ def main():
     ready.record()
     torch.cuda.synchronize()
 
+    # Data-parallel runs put the step on a high-priority stream: the dependent chain (with its SyncBN collectives)
+    # is served first, the weight-gradient and coordinate-map streams (default priority) fill what is left
+    # (measured on one rank with every collective active: 74.7 -> 75.5 scans/s).  LIDOG_MAIN_STREAM_PRIORITY
+    # overrides (-1 = high, "none" = run on the default stream).
+    prio = os.environ.get("LIDOG_MAIN_STREAM_PRIORITY", "-1" if (world > 1 or single_dp) else "none")
+    main_stream = torch.cuda.Stream(priority=int(prio)) if prio != "none" else None
+
     def run(i):
+        if main_stream is not None:
+            with torch.cuda.stream(main_stream):
+                return run_(i)
+        return run_(i)
+
+    def run_(i):
         if args.no_prefetch:
             return step.training_step(batches[i % 2])
         return step.training_step(batches[i % 2], prefetch=batches[(i + 1) % 2], prefetch_ready=ready)
