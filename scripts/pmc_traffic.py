@@ -13,7 +13,7 @@ import sys
 
 def per_kernel(d, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             k = r["Kernel_Name"]
