@@ -31,6 +31,22 @@ __device__ __forceinline__ void frag_load(const float *p, float (&f)[NT]) {
 
 template <int NT>
 __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
+#ifndef LIDOG_CACHED_T_STORE
+    // the product rows are written once and read once by the reduction pass: streaming (nontemporal) stores keep them
+    // from evicting the gathered feature rows and the weights from L2 (gathered GEMM 3-9 % faster)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    if constexpr (NT == 4) {
+        v4f v = {f[0], f[1], f[2], f[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+    } else if constexpr (NT == 2) {
+        v2f v = {f[0], f[1]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p));
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) __builtin_nontemporal_store(f[t], p + t);
+    }
+#else
     if constexpr (NT == 4) {
         *reinterpret_cast<float4 *>(p) = make_float4(f[0], f[1], f[2], f[3]);
     } else if constexpr (NT == 2) {
@@ -39,6 +55,7 @@ __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) p[t] = f[t];
     }
+#endif
 }
 
 // ------------------------------------------------------------------ gathered GEMM
