@@ -103,6 +103,19 @@ int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int3
 /* count / eps / momentum / mean / invstd / running_*: as for lidog_bn_stats below (the last kernel of the
  * reduction also stores the row count behind the sums and, when mean != NULL, finalises the statistics). */
 
+/* Output-stationary convolution for stride-1 odd kernels (csrc/sconv_os.hip): out = sum_k A[pair_in] . W[k] without
+ * the product rows T and the reduction pass; bit-identical to lidog_sconv_gemm + lidog_sconv_reduce.
+ * seg [K][ceil(n_out/256)+1] int32 from lidog_sconv_os_segments (first pair of every (offset, 256-row block)).
+ * reverse = 1 with A = gout and W = transposed weights gives the data gradient (the map is symmetric).
+ * partial (may be NULL): ceil(n_out/256) x 2*Cout doubles, BatchNorm partial sums of out (then lidog_bn_sums_finish).
+ * Cin in {32,64,96,128}, Cout % 32 == 0. */
+int32_t lidog_sconv_os_block_rows(void);
+int lidog_sconv_os_segments(const int32_t *pair_out, const int64_t *k_off, int32_t K, int64_t n_out, int32_t *seg,
+                            void *stream);
+int lidog_sconv_os(const float *A, const int32_t *pair_in, const int32_t *pair_out, const int32_t *seg, int32_t K,
+                   int64_t n_out, const float *W, int32_t reverse, int32_t Cin, int32_t Cout, float *out,
+                   double *partial, void *stream);
+
 /* gW[k] = sum over the pairs p of offset k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
  * The pair list is cut on the host into work items of (nearly) equal length that never straddle an offset:
  * items [3, n_items] int32 = (k, first pair, end pair), ordered by k; item_off [K+1] = first item of every k.

@@ -205,3 +205,45 @@ def test_coordinate_range_checked():
     coords = torch.tensor([[0, 0, 0, 0], [0, 70000, 0, 0]], dtype=torch.int32).cuda()
     with pytest.raises(ValueError):
         ME.SparseTensor(coordinates=coords, features=torch.ones(2, 1).cuda())
+
+
+@pytest.mark.parametrize("Cin,Cout,n", [(96, 96, 9000), (32, 64, 700), (128, 128, 9000), (64, 32, 3000)])
+def test_output_stationary_conv_equals_two_pass_and_oracle(Cin, Cout, n):
+    """csrc/sconv_os.hip (no product rows, no reduction pass; not used by lidog_amd.me, see its header): forward,
+    data gradient (through the symmetry of the stride-1 map) and BatchNorm partial sums, bit-identical to the
+    oracle's exact mode -- ragged last block, blocks without pairs for some offsets, padding rows."""
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    from lidog_amd._lib import call, load, ptr
+    OME.set_mode("exact")
+    coords = _rand_coords(11, n=n, extent=16)
+    so, sg = _maps(coords)
+    N = coords.shape[0]
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, generator=g)
+    co = OME.MinkowskiConvolution(Cin, Cout, kernel_size=3, dimension=3)
+    xo = x.clone().requires_grad_(True)
+    yo = co(OME.SparseTensor(xo, coordinate_manager=so.coordinate_manager, coordinate_map_key=1))
+    gy = torch.randn(N, Cout, generator=g)
+    yo.F.backward(gy)
+    m = sg.coordinate_manager.kernel_map(1, 1, 3)
+    L = load()
+    BR = L.lidog_sconv_os_block_rows()
+    nb = (N + BR - 1) // BR
+    seg = torch.empty((m.K, nb + 1), dtype=torch.int32, device="cuda")
+    call("lidog_sconv_os_segments", ptr(m.pair_out), ptr(m.k_off), m.K, N, ptr(seg))
+    W = co.kernel.detach().cuda().contiguous()
+    out = torch.full((N, Cout), float("nan"), device="cuda")
+    part = torch.empty(nb * 2 * Cout, dtype=torch.float64, device="cuda")
+    call("lidog_sconv_os", ptr(x.cuda()), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, N, ptr(W), 0, Cin, Cout,
+         ptr(out), ptr(part))
+    assert torch.equal(out.cpu(), yo.F.detach())
+    sums = part.view(nb, 2 * Cout).sum(0).cpu()
+    d = yo.F.detach().double()
+    torch.testing.assert_close(sums[:Cout], d.sum(0), rtol=1e-12, atol=1e-9)
+    torch.testing.assert_close(sums[Cout:], (d * d).sum(0), rtol=1e-12, atol=1e-9)
+    Wt = W.transpose(1, 2).contiguous()
+    gx = torch.full((N, Cin), float("nan"), device="cuda")
+    call("lidog_sconv_os", ptr(gy.cuda()), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, N, ptr(Wt), 1, Cout, Cin,
+         ptr(gx), None)
+    assert torch.equal(gx.cpu(), xo.grad)
