@@ -19,6 +19,8 @@ sys.path.insert(0, REPO)
 # maps); with the runtime's default of 4 hardware queues two of them can land on the same queue and serialise
 # (measured: the weight-gradient stream then overlaps nothing).  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the host driver of this pool only supports dmabuf IPC (RCCL's peer buffers); normally already exported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
