@@ -181,7 +181,8 @@ int lidog_bev_winner(const int32_t *coords, int64_t n, const int32_t *lut_x, con
                      int32_t *pixel /*[n] linear b*H*W+py*W+px or -1*/, void *stream);
 /* winner/pixel/n: as produced by lidog_bev_winner for the same rows (only windows that contain a cell of an
  * occupied pixel are computed; the rest of out/argsrc is filled with 0 / -1).
- * rowbits (may be NULL): uint64 [B*C*Ho][ceil(Wo/64)], bit x of row (b,c,yo) set for every computed window: the
+ * rowbits (may be NULL; when given, argsrc is written for the computed windows only and NOT filled elsewhere):
+ * uint64 [B*C*Ho][ceil(Wo/64)], bit x of row (b,c,yo) set for every computed window: the
  * structural support of `out` (a superset of argsrc >= 0) in the form lidog_conv2d_support keeps at the start of
  * its `act` buffer -- pass that buffer here and call lidog_conv2d_support(NULL, ...). */
 int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, const int32_t *pixel, int64_t n,
@@ -189,9 +190,11 @@ int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, con
                        float *out /*[B,C,Ho,Wo]*/,
                        int32_t *argsrc /*[B,C,Ho,Wo] row*C+c of the arg-max cell or -1*/, uint64_t *rowbits,
                        void *stream);
+/* rowbits / Wo (rowbits may be NULL): the bitmasks lidog_bev_pool_fwd wrote -- argsrc is then read only where a bit
+ * is set (it is NOT initialised elsewhere when the forward call was given bitmasks) */
 int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems, const int32_t *winner,
                        const int32_t *pixel, int64_t n, int32_t C, float *gcell /*[n,C] zeroed scratch*/,
-                       float *gfeats /*[n,C]*/, void *stream);
+                       float *gfeats /*[n,C]*/, const uint64_t *rowbits, int32_t Wo, void *stream);
 
 /* ------------------------------------------------------------------ dense 2-D BEV head (MFMA)
  * Replaces nn.Conv2d(k3,s2,p1,bias=False) x2 and nn.Conv2d(k1) of Encoder2D

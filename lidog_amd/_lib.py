@@ -45,7 +45,7 @@ SIGNATURES = {
     "lidog_add": [_p, _p, _i64, _p, _p],
     "lidog_bev_winner": [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_bev_pool_fwd": [_p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
-    "lidog_bev_pool_bwd": [_p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p],
+    "lidog_bev_pool_bwd": [_p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p],
     "lidog_conv2d_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_conv2d_dgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_conv2d_wgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p],

@@ -208,7 +208,8 @@ extern "C" int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *
     hipStream_t st = (hipStream_t)stream;
     // windows without an occupied pixel: max over zeros = 0, no source cell
     if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)total, st) != hipSuccess) return 1;
-    if (hipMemsetAsync(argsrc, 0xff, sizeof(int32_t) * (size_t)total, st) != hipSuccess) return 1;
+    // with row bitmasks argsrc is only ever read where a bit is set (lidog_bev_pool_bwd), i.e. where it was written
+    if (!rowbits && hipMemsetAsync(argsrc, 0xff, sizeof(int32_t) * (size_t)total, st) != hipSuccess) return 1;
     const int words = (Wo + 63) / 64;
     if (rowbits && hipMemsetAsync(rowbits, 0, sizeof(uint64_t) * (size_t)B * C * Ho * words, st) != hipSuccess) return 1;
     if (n == 0) return 0;
@@ -238,6 +239,27 @@ __global__ __launch_bounds__(256) void k_bev_pool_bwd_cells(const float *__restr
     if (s >= 0) atomicAdd(&gcell[s], gout[e]);
 }
 
+// the same through the row bitmasks of lidog_bev_pool_fwd: only computed windows can have a source cell, so one
+// lane per 64-column word walks its set bits (0.34 -> ~0.05 ms on a LiDAR sweep: 95 % of the words are zero)
+__global__ __launch_bounds__(256) void k_bev_pool_bwd_cells_bits(const float *__restrict__ gout,
+                                                                 const int32_t *__restrict__ argsrc,
+                                                                 const unsigned long long *__restrict__ rowbits,
+                                                                 int64_t n_words, int words, int Wo, float *gcell) {
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= n_words) return;
+    unsigned long long m = rowbits[wi];
+    if (m == 0) return;
+    const int64_t row = wi / words;
+    const int x0 = (int)(wi - row * words) * 64;
+    const int64_t base = row * Wo + x0;
+    while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int32_t s = argsrc[base + b];
+        if (s >= 0) atomicAdd(&gcell[s], gout[base + b]);
+    }
+}
+
 // index_put's backward is a gather: EVERY row that targets a pixel receives that pixel's gradient
 __global__ __launch_bounds__(256) void k_bev_pool_bwd_rows(const float *__restrict__ gcell,
                                                            const int32_t *__restrict__ winner,
@@ -255,9 +277,15 @@ __global__ __launch_bounds__(256) void k_bev_pool_bwd_rows(const float *__restri
 
 extern "C" int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems,
                                   const int32_t *winner, const int32_t *pixel, int64_t n, int32_t C, float *gcell,
-                                  float *gfeats, void *stream) {
+                                  float *gfeats, const uint64_t *rowbits, int32_t Wo, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (n_out_elems)
+    if (n_out_elems && rowbits) {
+        LIDOG_REQUIRE(Wo > 0 && n_out_elems % Wo == 0, "bev_pool_bwd: Wo must divide the number of output elements");
+        const int words = (Wo + 63) / 64;
+        const int64_t n_words = n_out_elems / Wo * words;
+        k_bev_pool_bwd_cells_bits<<<(unsigned)cdiv64(n_words, 256), 256, 0, st>>>(
+            gout, argsrc, reinterpret_cast<const unsigned long long *>(rowbits), n_words, words, Wo, gcell);
+    } else if (n_out_elems)
         k_bev_pool_bwd_cells<<<(unsigned)cdiv64(n_out_elems, 256), 256, 0, st>>>(gout, argsrc, n_out_elems, gcell);
     if (n)
         k_bev_pool_bwd_rows<<<(unsigned)cdiv64(n * C, 256), 256, 0, st>>>(gcell, winner, pixel, n, C, gfeats);
