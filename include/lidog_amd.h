@@ -91,6 +91,7 @@ int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, cons
 /* out[o][:] = sum over k ascending of T[pos[k*n + o]][:] (skipping -1), plus bias if not NULL.
  * The gather->GEMM->scatter-add order of the ME CPU algorithm, without atomics. */
 int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
+                       const float *addend /* [n,C] added last (may be NULL): a second gradient of the same tensor */,
                        float *out, void *stream);
 
 /* lidog_sconv_reduce with the BatchNorm statistics of `out` folded into the same pass: sums[0..C) = sum over

@@ -307,6 +307,7 @@ __device__ __forceinline__ float4 reduce_row(const float4 *__restrict__ T, const
 
 __global__ __launch_bounds__(256) void k_sconv_reduce4(const float4 *__restrict__ T, const int32_t *__restrict__ pos,
                                                        int64_t n, int K, int C4, const float4 *__restrict__ bias,
+                                                       const float4 *__restrict__ addend,
                                                        float4 *__restrict__ out) {
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * C4) return;
@@ -316,6 +317,10 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4(const float4 *__restrict_
     if (bias) {
         float4 b = bias[c4];
         acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    if (addend) {  // a second gradient of the same tensor (the residual branch): the add autograd would launch
+        float4 a = addend[idx];
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
     out[idx] = acc;
 }
@@ -337,13 +342,15 @@ __global__ __launch_bounds__(256) void k_sconv_reduce1(const float *__restrict__
 }
 
 extern "C" int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C,
-                                  const float *bias, float *out, void *stream) {
+                                  const float *bias, const float *addend, float *out, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return 0;
+    LIDOG_REQUIRE(addend == nullptr || C % 4 == 0, "sconv_reduce: an addend needs C % 4 == 0");
     if (C % 4 == 0) {
         int C4 = C / 4;
         k_sconv_reduce4<<<(unsigned)cdiv64(n * C4, 256), 256, 0, st>>>((const float4 *)T, pos, n, K, C4,
-                                                                       (const float4 *)bias, (float4 *)out);
+                                                                       (const float4 *)bias, (const float4 *)addend,
+                                                                       (float4 *)out);
     } else {
         k_sconv_reduce1<<<(unsigned)cdiv64(n * C, 256), 256, 0, st>>>(T, pos, n, K, C, bias, out);
     }

@@ -594,7 +594,7 @@ class _SparseConvFn(torch.autograd.Function):
     (k2 s2) -> the data gradient scatters straight into `gin`."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, m, swap, single_out, single_in, stats=None):
+    def forward(ctx, x, W, bias, m, swap, single_out, single_in, stats=None, skip=False):
         """`stats`: optional StatsRequest of the BatchNorm that follows; when the output goes through the reduction
         pass, that pass also produces the fp64 sums of `out` (and, for a local BatchNorm, mean / invstd / running
         statistics), returned in the request."""
@@ -632,18 +632,23 @@ class _SparseConvFn(torch.autograd.Function):
                          ptr(stats.running_mean), ptr(stats.running_var))
                 stats.sums = sums
             else:
-                call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out))
+                call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), None, ptr(out))
         ctx.save_for_backward(x, W3)
         ctx.m, ctx.swap, ctx.single_in, ctx.has_bias, ctx.w_shape = m, swap, single_in, bias is not None, W.shape
         ctx.w_param, ctx.b_param = W, bias
+        if skip:
+            # second output = the input itself (the residual branch of a BasicBlock): its gradient comes back to
+            # this node and is added by the data gradient's reduction pass instead of by an autograd add kernel
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, gskip=None):
         x, W3 = ctx.saved_tensors
         m, swap = ctx.m, ctx.swap
         K, Cin, Cout = W3.shape
         gout = gout.contiguous()
+        gskip = gskip.contiguous() if gskip is not None else None
         identity = isinstance(m, _IdentityMap)
         if identity:
             g_in = g_out = m.rows
@@ -681,7 +686,10 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
-                call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(gx))
+                add = gskip if (gskip is not None and Cin % 4 == 0) else None
+                call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(add), ptr(gx))
+                if add is not None:
+                    gskip = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if Cout <= 16:
                 gb = _grad_out(ctx.b_param, (1, Cout))
@@ -690,7 +698,9 @@ class _SparseConvFn(torch.autograd.Function):
                 call("lidog_colsum", ptr(gout), gout.shape[0], Cout, ptr(gb), ptr(ws))
             else:
                 gb = gout.sum(dim=0, keepdim=True)
-        return gx, gW, gb, None, None, None, None, None
+        if gskip is not None:   # paths without a reduction pass (1x1, k2 s2) or no data gradient asked for
+            gx = gskip if gx is None else gx + gskip
+        return gx, gW, gb, None, None, None, None, None, None
 
 
 def _bn_ws(C, hw, dev):
@@ -855,7 +865,9 @@ class _ConvBase(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
 
-    def forward(self, x, stats=None):
+    def forward(self, x, stats=None, skip=False):
+        """`skip=True` returns (conv(x), x'): x' is x again, but routed through this convolution's autograd node
+        so that the gradient of a residual branch taken from x' is added inside the data gradient's reduction"""
         cm, s_in = x.coordinate_manager, x.coordinate_map_key
         if self.kernel_volume == 1 and self.stride == 1:
             m, s_out, swap, single_out, single_in = cm.identity_map(x.F.shape[0]), s_in, False, True, True
@@ -874,7 +886,10 @@ class _ConvBase(nn.Module):
             cm.trace.append(((s_out, s_in, self.kernel_size, self.dilation), self.in_channels, self.out_channels))
             swap, single_in = True, False
             single_out = self.stride == self.kernel_size and self.stride > 1
-        out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in, stats)
+        out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in, stats, skip)
+        if skip:
+            return (SparseTensor(out[0], coordinate_manager=cm, coordinate_map_key=s_out),
+                    SparseTensor(out[1], coordinate_manager=cm, coordinate_map_key=s_in))
         return SparseTensor(out, coordinate_manager=cm, coordinate_map_key=s_out)
 
 
@@ -945,13 +960,17 @@ class MinkowskiReLU(nn.Module):
         return x._like(_ReLUFn.apply(f, inplace))
 
 
-def conv_bn(conv, bn_module, x, relu=False, residual=None):
+def conv_bn(conv, bn_module, x, relu=False, residual=None, skip=False):
     """convolution + BatchNorm (+ residual add + ReLU): the BN statistics come out of the convolution's
-    reduction pass, the affine/add/ReLU is one fused elementwise pass"""
+    reduction pass, the affine/add/ReLU is one fused elementwise pass.  `skip`: also return x routed through the
+    convolution's autograd node (MinkowskiConvolution.forward)."""
     bn = bn_module.bn
     req = None
     if bn.training or not bn.track_running_stats:
         req = StatsRequest(bn, bn_module._sync_group() is not None)
+    if skip:
+        y, x_alias = conv(x, stats=req, skip=True)
+        return bn_module(y, relu=relu, residual=residual, stats=req), x_alias
     y = conv(x, stats=req)
     return bn_module(y, relu=relu, residual=residual, stats=req)
 
@@ -1028,7 +1047,13 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = conv_bn(self.conv1, self.norm1, x, relu=True)
+        if x.F.requires_grad:
+            # the residual branch takes x from conv1's autograd node, so the two gradients of x (conv1's data
+            # gradient and the residual's / the downsample convolution's) are summed by conv1's reduction pass, not
+            # by a separate add kernel
+            out, x = conv_bn(self.conv1, self.norm1, x, relu=True, skip=True)
+        else:
+            out = conv_bn(self.conv1, self.norm1, x, relu=True)
         residual = x if self.downsample is None else self.downsample(x)
         return conv_bn(self.conv2, self.norm2, out, relu=True, residual=residual)
 

@@ -40,7 +40,7 @@ for s, k, Cin, Cout in cases:
     slabs = L.lidog_sconv_wgrad_slabs(Cin, Cout, ns)
     part = torch.empty(max(slabs, 1), Cin, Cout, device="cuda")
     t_g = timeit(lambda: ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T, None))
-    t_r = timeit(lambda: call("lidog_sconv_reduce", ptr(T), ptr(m.pos_out), m.n_out, m.K, Cout, None, ptr(out)))
+    t_r = timeit(lambda: call("lidog_sconv_reduce", ptr(T), ptr(m.pos_out), m.n_out, m.K, Cout, None, None, ptr(out)))
     t_d = timeit(lambda: ME._gemm(g, m.pair_out, Wt, None, m, Cout, Cin, T2, None))
     t_w = timeit(lambda: call("lidog_sconv_wgrad", ptr(x), ptr(m.pair_in), ptr(g), ptr(m.pair_out), ptr(items), ns, ptr(item_off), m.K, Cin, Cout, ptr(part), ptr(gW)))
     fl = 2.0 * m.P * Cin * Cout / 1e9

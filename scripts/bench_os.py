@@ -34,14 +34,14 @@ for s, Cin, Cout in cases:
     out = torch.empty(n, Cout, device="cuda")
     part = torch.empty(nb * 2 * Cout, dtype=torch.float64, device="cuda")
     t_g = timeit(lambda: ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T, None))
-    t_r = timeit(lambda: call("lidog_sconv_reduce", ptr(T), ptr(m.pos_out), n, m.K, Cout, None, ptr(ref)))
+    t_r = timeit(lambda: call("lidog_sconv_reduce", ptr(T), ptr(m.pos_out), n, m.K, Cout, None, None, ptr(ref)))
     t_o = timeit(lambda: call("lidog_sconv_os", ptr(x), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, n, ptr(W), 0, Cin, Cout, ptr(out), ptr(part)))
     eq = torch.equal(out, ref)
     # data gradient: A = g [n, Cout], Wt [K][Cout][Cin]
     g = torch.randn(n, Cout, device="cuda"); Wt = W.transpose(1, 2).contiguous()
     T2 = torch.empty(m.P, Cin, device="cuda"); gref = torch.empty(n, Cin, device="cuda"); gx = torch.empty(n, Cin, device="cuda")
     ME._gemm(g, m.pair_out, Wt, None, m, Cout, Cin, T2, None)
-    call("lidog_sconv_reduce", ptr(T2), ptr(m.pos_in), n, m.K, Cin, None, ptr(gref))
+    call("lidog_sconv_reduce", ptr(T2), ptr(m.pos_in), n, m.K, Cin, None, None, ptr(gref))
     ok2 = "-"
     if Cout <= 128:
         call("lidog_sconv_os", ptr(g), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, n, ptr(Wt), 1, Cout, Cin, ptr(gx), None)
