@@ -245,18 +245,25 @@ __global__ __launch_bounds__(256) void k_bev_pool_bwd_cells_bits(const float *__
                                                                  const int32_t *__restrict__ argsrc,
                                                                  const unsigned long long *__restrict__ rowbits,
                                                                  int64_t n_words, int words, int Wo, float *gcell) {
-    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (wi >= n_words) return;
-    unsigned long long m = rowbits[wi];
-    if (m == 0) return;
-    const int64_t row = wi / words;
-    const int x0 = (int)(wi - row * words) * 64;
-    const int64_t base = row * Wo + x0;
-    while (m) {
-        const int b = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int32_t s = argsrc[base + b];
-        if (s >= 0) atomicAdd(&gcell[s], gout[base + b]);
+    // a wave owns 64 consecutive words; every non-zero one is then handled by the whole wave, lane = column of
+    // the word (coalesced reads of the source map and of the gradient)
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) - lane;
+    const int64_t wi = w0 + lane;
+    const unsigned long long mine = wi < n_words ? rowbits[wi] : 0ull;
+    unsigned long long todo = __ballot(mine != 0ull);
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const unsigned long long m = __shfl(mine, j);
+        const int64_t wj = w0 + j;
+        const int64_t row = wj / words;
+        const int x = (int)(wj - row * words) * 64 + lane;
+        if ((m >> lane) & 1ull) {
+            const int64_t e = row * Wo + x;
+            const int32_t s = argsrc[e];
+            if (s >= 0) atomicAdd(&gcell[s], gout[e]);
+        }
     }
 }
 
