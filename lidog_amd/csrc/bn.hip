@@ -343,6 +343,53 @@ static unsigned ew_grid(int64_t n) {
     return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
+// NCHW images (hw > 1): workgroup (plane, chunk) -- the channel and its constants are fixed per workgroup, no
+// per-element index arithmetic (the generic kernels spend a 64-bit division per element on it)
+__global__ __launch_bounds__(256) void k_bn_apply_plane(const float *__restrict__ x, int64_t hw, int C,
+                                                        const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd,
+                                                        const float *__restrict__ w, const float *__restrict__ b,
+                                                        const float *__restrict__ res, int relu,
+                                                        float *__restrict__ y) {
+    const int64_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float m = mean[c], sc = invstd[c] * w[c], sh = b[c], is = invstd[c], ww = w[c];
+    (void)sc;
+    const int64_t chunk = (hw + gridDim.y - 1) / gridDim.y;
+    const int64_t i0 = plane * hw + (int64_t)blockIdx.y * chunk;
+    const int64_t i1 = (blockIdx.y + 1) * chunk < hw ? i0 + chunk : plane * hw + hw;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float v = (x[i] - m) * is * ww + sh;   // same operation order as k_bn_apply
+        if (res) v += res[i];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_plane(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ ry, int64_t hw, int C,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ w,
+                                                            const double *__restrict__ sums, double inv_count,
+                                                            float *__restrict__ dx, float *__restrict__ dres) {
+    const int64_t plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const double ic = (inv_count > 0) ? inv_count : 1.0 / sums[2 * C];
+    const float m = mean[c], is = invstd[c], ww = w[c];
+    const float m0 = (float)(sums[c] * ic), m1 = (float)(sums[C + c] * ic);
+    const int64_t chunk = (hw + gridDim.y - 1) / gridDim.y;
+    const int64_t i0 = plane * hw + (int64_t)blockIdx.y * chunk;
+    const int64_t i1 = (blockIdx.y + 1) * chunk < hw ? i0 + chunk : plane * hw + hw;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float g = dy[i];
+        if (ry && !(ry[i] > 0.f)) g = 0.f;
+        const float xh = (x[i] - m) * is;
+        dx[i] = (g - m0 - xh * m1) * is * ww;   // same operation order as k_bn_bwd_apply
+        if (dres) dres[i] = g;
+    }
+}
+
 extern "C" int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean,
                               const float *invstd, const float *w, const float *b, const float *residual,
                               int32_t relu, float *y, void *stream) {
@@ -353,6 +400,11 @@ extern "C" int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, 
         k_bn_apply4<<<ew_grid(total / 4), 256, 0, st>>>((const float4 *)x, total / 4, C / 4, (const float4 *)mean,
                                                         (const float4 *)invstd, (const float4 *)w, (const float4 *)b,
                                                         (const float4 *)residual, relu, (float4 *)y);
+    } else if (hw >= 1024) {
+        int chunks = (int)cdiv64(hw, 8192);
+        if (chunks > 64) chunks = 64;
+        k_bn_apply_plane<<<dim3((unsigned)(n * C), (unsigned)chunks), 256, 0, st>>>(x, hw, C, mean, invstd, w, b,
+                                                                                   residual, relu, y);
     } else {
         k_bn_apply<<<ew_grid(total), 256, 0, st>>>(x, total, C, hw, mean, invstd, w, b, residual, relu, y);
     }
@@ -447,6 +499,11 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
                                                           (const float4 *)relu_y, total4, C4, mean, invstd, w, sums,
                                                           count > 0 ? 1.0 / count : -1.0, (float4 *)dx,
                                                           (float4 *)dres);
+    } else if (total > 0 && hw >= 1024) {
+        int chunks = (int)cdiv64(hw, 8192);
+        if (chunks > 64) chunks = 64;
+        k_bn_bwd_apply_plane<<<dim3((unsigned)(n * C), (unsigned)chunks), 256, 0, st>>>(
+            dy, x, relu_y, hw, C, mean, invstd, w, sums, count > 0 ? 1.0 / count : -1.0, dx, dres);
     } else if (total > 0)
         k_bn_bwd_apply<<<ew_grid(total), 256, 0, st>>>(dy, x, relu_y, total, C, hw, mean, invstd, w, sums,
                                                        count > 0 ? 1.0 / count : -1.0,
