@@ -649,6 +649,42 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cout8(const float *__restri
 // gW[k][e] = sum of the partial slots of the work items of offset k (item_off[k] .. item_off[k+1]), `per` slots
 // per item.  64 elements x 4 slot lanes per workgroup; each lane adds every 4th slot in order, the four lane sums
 // are combined in lane order (deterministic).
+// n % 4 == 0: 16 slot lanes x 16 element lanes of float4 (64 elements per workgroup as below, four times the bytes
+// in flight); slot lane l adds slots l, l + 16, ... in two chains, the 16 lane sums are combined in lane order
+__global__ __launch_bounds__(256) void k_items_sum4(const float4 *__restrict__ partial,
+                                                    const int32_t *__restrict__ item_off, int per, int64_t n4,
+                                                    float4 *__restrict__ out) {
+    __shared__ float4 red[256];
+    const int lane_e = threadIdx.x & 15, lane_s = threadIdx.x >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + lane_e;
+    const int k = blockIdx.y;
+    const int64_t s0 = (int64_t)item_off[k] * per, s1 = (int64_t)item_off[k + 1] * per;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (e < n4) {
+        int64_t sl = s0 + lane_s;
+        for (; sl + 16 < s1; sl += 32) {
+            const float4 u = partial[sl * n4 + e], v = partial[(sl + 16) * n4 + e];
+            a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+            a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+        }
+        if (sl < s1) {
+            const float4 u = partial[sl * n4 + e];
+            a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+        }
+    }
+    red[threadIdx.x] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (lane_s == 0 && e < n4) {
+        float4 t = red[lane_e];
+#pragma unroll
+        for (int l = 1; l < 16; ++l) {
+            const float4 u = red[16 * l + lane_e];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        out[(int64_t)k * n4 + e] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_items_sum(const float *__restrict__ partial,
                                                    const int32_t *__restrict__ item_off, int per, int64_t n,
                                                    float *__restrict__ out) {
@@ -733,7 +769,11 @@ extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const fl
         }
     }
     int64_t n = (int64_t)Cin * Cout;
-    k_items_sum<<<dim3((unsigned)cdiv64(n, 64), (unsigned)K), 256, 0, st>>>(partial, item_off, per, n, gW);
+    if (n % 4 == 0)
+        k_items_sum4<<<dim3((unsigned)cdiv64(n / 4, 16), (unsigned)K), 256, 0, st>>>(
+            (const float4 *)partial, item_off, per, n / 4, (float4 *)gW);
+    else
+        k_items_sum<<<dim3((unsigned)cdiv64(n, 64), (unsigned)K), 256, 0, st>>>(partial, item_off, per, n, gW);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
