@@ -128,25 +128,26 @@ def _side_stream(device):
 class _WgradLane:
     """Second stream of the backward pass.  A weight gradient depends only on tensors that exist when its
     convolution's backward starts and nothing in the backward chain depends on it, so it is queued on a side
-    stream and runs next to the data-gradient chain (the chain is a sequence of dependent kernels with tails and
-    many microsecond-sized BatchNorm launches; SyncBatchNorm adds a collective per layer to it).  Only used when
-    the gradient is written straight into the optimiser's flat buffer (me._grad_out): a fresh tensor would be
-    touched by autograd on the main stream right after backward() returns it.
+    stream.  It is forked BEHIND the data gradient's GEMM of its layer: two matrix kernels next to each other gain
+    nothing (same pipe), but the weight gradient then runs next to what follows that GEMM on the main stream -- the
+    per-row reduction, the BatchNorm backward kernels of the next layer, their microsecond-sized follow-ups and, in
+    data-parallel runs, the SyncBatchNorm collectives -- all bandwidth- or latency-bound.  Measured on one GPU
+    (bs 4): 77.7 -> 81.2 scans/s; forked BEFORE the GEMM (LIDOG_BACKWARD_OVERLAP=1) 79.9, with every data-gradient
+    GEMM sharing the chip with a weight gradient (its timed duration grows by 45 %, against 6 % behind the GEMM,
+    where only the tail of the previous layer's weight gradient can reach into it).
+    Only used when the gradient is written straight into the optimiser's flat buffer (me._grad_out): a fresh tensor
+    would be touched by autograd on the main stream right after backward() returns it.
     Tensors read on the side stream are kept alive until the join (also keeps autograd from accumulating into
     them in place); the join is an engine callback at the end of the backward pass."""
 
-    # LIDOG_BACKWARD_OVERLAP=1 / 0 forces it on / off; default: on in data-parallel runs only.  On one GPU the
-    # backward chain has no collectives to wait for and the second stream buys 2.7 % (measured, bs 4) while every
-    # data-gradient kernel shares the chip with a weight gradient, which blurs per-kernel timings.
-    _env = os.environ.get("LIDOG_BACKWARD_OVERLAP", "auto")
-    enabled = {"1": True, "0": False}.get(_env)
+    # LIDOG_BACKWARD_OVERLAP: unset / 2 = behind the GEMM (default), 1 = before it, 0 = everything on one stream
+    _env = os.environ.get("LIDOG_BACKWARD_OVERLAP", "2")
+    enabled = _env != "0"
+    mode = 1 if _env == "1" else 2
     _lanes = {}
 
     @classmethod
     def active(cls):
-        if cls.enabled is None:
-            import torch.distributed as dist
-            return dist.is_available() and dist.is_initialized()
         return cls.enabled
 
     def __init__(self, device):
@@ -181,10 +182,11 @@ class _WgradLane:
             self.keep = []
 
 
-def set_backward_overlap(on):
-    """weight gradients on a second stream (True), in line on the current stream (False), or decided per run:
-    second stream when torch.distributed is initialised (None, the default)"""
-    _WgradLane.enabled = None if on is None else bool(on)
+def set_backward_overlap(on, mode=2):
+    """weight gradients on a second stream (True; mode 2 = forked behind the data gradient's GEMM, 1 = before it)
+    or in line on the current stream (False)"""
+    _WgradLane.enabled = bool(on)
+    _WgradLane.mode = 1 if mode == 1 else 2
 
 
 def wgrad_lane(device):
@@ -658,8 +660,11 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             g_in, g_out, pos_i, n_in = m.pair_out, m.pair_in, m.pos_out, m.n_out
         gx = gW = gb = None
-        if ctx.needs_input_grad[1]:
-            # queued before the data gradient so that the side stream can start right away
+        lane_on = _WgradLane.active()
+        # forked behind the data gradient's GEMM (see _WgradLane), or before everything in mode 1
+        behind = lane_on and _WgradLane.mode == 2
+
+        def queue_wgrad():
             gW = _grad_out(ctx.w_param, W3.shape)
             items, n_items, item_off = _wgrad_items(m, Cin, Cout)
             slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, n_items)
@@ -668,13 +673,16 @@ class _SparseConvFn(torch.autograd.Function):
                 partial = torch.empty((max(slabs, 1), Cin, Cout), dtype=torch.float32, device=x.device)
                 call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items,
                      ptr(item_off), K, Cin, Cout, ptr(partial), ptr(gW))
-            if gW is not None and _WgradLane.active():
+            if gW is not None and lane_on:
                 with torch.cuda.stream(_WgradLane.get(x.device).fork(x, gout, m)):
                     wgrad(gW)
             else:
                 gW = gW if gW is not None else torch.empty_like(W3)
                 wgrad(gW)
-            gW = gW.view(ctx.w_shape)
+            return gW.view(ctx.w_shape)
+
+        if ctx.needs_input_grad[1] and not behind:
+            gW = queue_wgrad()
         if ctx.needs_input_grad[0]:
             Wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
             call("lidog_transpose_kernel", ptr(W3), K, Cin, Cout, ptr(Wt))
@@ -686,10 +694,14 @@ class _SparseConvFn(torch.autograd.Function):
             else:
                 T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
+                if ctx.needs_input_grad[1] and behind:
+                    gW = queue_wgrad()
                 add = gskip if (gskip is not None and Cin % 4 == 0) else None
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(add), ptr(gx))
                 if add is not None:
                     gskip = None
+        if ctx.needs_input_grad[1] and gW is None:
+            gW = queue_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if Cout <= 16:
                 gb = _grad_out(ctx.b_param, (1, Cout))
