@@ -77,3 +77,30 @@ def test_training_with_prefetch_follows_the_same_trajectory():
     assert l0 == l1, (l0, l1)                 # MinkUNet34 has no atomics: bit-identical
     for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_second_backward_stream_does_not_change_the_trajectory(mode):
+    """Weight gradients on the second stream (forked before / behind the data gradient's GEMM, joined by the engine
+    callback at the end of backward) against everything on one stream: the kernels and their inputs are the same,
+    so losses and parameters must be BIT-identical after four Adam steps -- any missing dependency between the two
+    streams would show up here (MinkUNet34 has no atomics)."""
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd.trainer import FlatAdam, SourceStep
+    batches = _batches()
+    torch.manual_seed(5)
+    m0 = lidog_amd.MinkUNet34(1, 7, 3).cuda().train()
+    m1 = copy.deepcopy(m0)
+    s0 = SourceStep(m0, FlatAdam(m0, lr=1e-3, weight_decay=1e-4))
+    s1 = SourceStep(m1, FlatAdam(m1, lr=1e-3, weight_decay=1e-4))
+    try:
+        ME.set_backward_overlap(False)
+        l0 = [float(s0.training_step(batches[i % 2])["loss"]) for i in range(4)]
+        ME.set_backward_overlap(True, mode)
+        l1 = [float(s1.training_step(batches[i % 2])["loss"]) for i in range(4)]
+    finally:
+        ME.set_backward_overlap(True, 2)
+    assert l0 == l1, (l0, l1)
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
