@@ -95,16 +95,28 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the raw C query: the python Stream object costs
+    ~9 us per call, 2 ms per training step over ~230 launches per pass)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_fns = {}
 
 
 def call(name, *args):
     """call a status-returning entry point on the current torch stream; raise on failure"""
-    L = load()
-    rc = getattr(L, name)(*args, stream())
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args, stream())
     if rc != 0:
-        raise RuntimeError(f"{name} failed ({rc}): {L.lidog_last_error().decode()}")
+        raise RuntimeError(f"{name} failed ({rc}): {load().lidog_last_error().decode()}")
 
 
 def require_gpu(t, what):
