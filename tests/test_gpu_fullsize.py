@@ -93,6 +93,60 @@ def test_bev_projection_properties_at_full_image():
     assert torch.equal(out, out2)                             # atomicMax winner map: deterministic
 
 
+def test_first_bev_convolution_over_the_support_of_a_real_scan():
+    """B = 50 m image of two 120 k-point scans (95 % empty): the convolution restricted to the active channels of
+    each pixel tile (row bitmasks written by the pooling kernel) against the dense kernels on the same image --
+    forward bit-identical, data gradient bit-identical wherever the pooling backward reads it, weight gradient
+    equal up to the order of the split sums; and the pooling backward through the bitmasks against the dense walk."""
+    import lidog_amd.me as ME
+    from lidog_amd import bev
+    from lidog_amd._lib import call, load, ptr
+    st, _ = _tensor("kitti120k", [5, 6])
+    n = st.F.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    feats = torch.rand(n, 96, device="cuda", generator=g).requires_grad_(True)
+    img = bev.sparse2super(ME.SparseTensor(feats, coordinate_manager=st.coordinate_manager, coordinate_map_key=1), 50.0)
+    act = bev.structural_support(img)
+    assert act is not None
+    B, Cin, H, W = img.shape
+    Cout = 256
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * 0.05
+    x = img.detach()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    L = load()
+    call("lidog_conv2d_support", None, B, Cin, H, W, ptr(act))
+    ws = torch.empty(9 * Cin * Cout, device="cuda")
+    y_d, y_s = torch.empty(B, Cout, Ho, Wo, device="cuda"), torch.empty(B, Cout, Ho, Wo, device="cuda")
+    call("lidog_conv2d_fwd", ptr(x), ptr(w), None, B, Cin, H, W, Cout, 3, 2, 1, ptr(y_d))
+    call("lidog_conv2d_fwd_sparse", ptr(x), ptr(w), ptr(act), B, Cin, H, W, Cout, ptr(y_s), ptr(ws))
+    assert torch.equal(y_s, y_d)
+    gy = torch.randn(B, Cout, Ho, Wo, device="cuda", generator=g)
+    gx_d, gx_s = torch.empty_like(x), torch.zeros_like(x)
+    call("lidog_conv2d_dgrad", ptr(gy), ptr(w), B, Cin, H, W, Cout, 3, 2, 1, ptr(gx_d), ptr(ws))
+    call("lidog_conv2d_dgrad_sparse", ptr(gy), ptr(w), ptr(act), B, Cin, H, W, Cout, ptr(gx_s), ptr(ws))
+    words = (W + 63) // 64
+    bits = act[:2 * B * Cin * H * words].view(torch.int64).view(B, Cin, H, words)
+    cols = torch.arange(W, device="cuda")
+    need = ((bits[..., cols // 64] >> (cols % 64)) & 1).bool()          # the windows the pooling kernel computed
+    assert 0.02 < float(need.float().mean()) < 0.10
+    assert torch.equal(x != 0, (x != 0) & need)                          # the image is zero outside its support
+    assert torch.equal(gx_s[need], gx_d[need])
+    gw_d, gw_s = torch.empty_like(w), torch.empty_like(w)
+    wsw = torch.empty(max(32 * w.numel(), L.lidog_conv2d_wgrad_sparse_ws(B, Cin, H, W, Cout)), device="cuda")
+    call("lidog_conv2d_wgrad", ptr(x), ptr(gy), B, Cin, H, W, Cout, 3, 2, 1, ptr(gw_d), None, ptr(wsw), wsw.numel())
+    call("lidog_conv2d_wgrad_sparse", ptr(x), ptr(gy), ptr(act), B, Cin, H, W, Cout, ptr(gw_s), ptr(wsw), wsw.numel())
+    assert float((gw_s - gw_d).abs().max()) <= 1e-5 * float(gw_d.abs().max())
+    # pooling backward: bitmask walk (what the model runs) == dense walk over the whole source map
+    gout = torch.randn_like(img)
+    winner, pixel, argsrc, _ = img.grad_fn.saved_tensors
+    img.backward(gout)
+    gcell, gfe = torch.zeros(n, 96, device="cuda"), torch.empty(n, 96, device="cuda")
+    src = torch.where(need, argsrc, torch.full_like(argsrc, -1))         # argsrc is only defined on the support
+    call("lidog_bev_pool_bwd", ptr(gout), ptr(src), gout.numel(), ptr(winner), ptr(pixel), n, 96, ptr(gcell), ptr(gfe),
+         None, W)
+    torch.testing.assert_close(feats.grad, gfe, rtol=1e-5, atol=1e-6)    # float atomics: equal up to summation order
+
+
 @pytest.mark.parametrize("name", ["c1_source8k", "c4_mix3d"])
 def test_source_training_configs_learn(name):
     """configs[0] (train_source MinkUNet34, 8k points, 0.1 m voxels, bs 4) and configs[3] (Mix3D union of two
