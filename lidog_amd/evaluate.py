@@ -33,14 +33,49 @@ def mean_iou(per_scan_iou):
 
 
 @torch.no_grad()
-def predict(model, coords, feats):
-    """validation / test forward: is_train=False (no BEV head, running BN statistics), arg-max class per voxel"""
+def predict(model, coords, feats, manager=None):
+    """validation / test forward: is_train=False (no BEV head, running BN statistics), arg-max class per voxel.
+    After the first call the coordinate maps of a batch are built in one go from the recorded trace of map uses
+    (ME.CoordinateManager.prepare: one host synchronisation instead of one per kernel map); `manager`: a manager
+    prepared ahead of time for these coordinates (Predictor / evaluate() build the next batch's while the current
+    forward pass runs)."""
     was_training = model.training
     model.eval()
-    out = model(ME.SparseTensor(coordinates=coords, features=feats))
+    trace = getattr(model, "_lidog_eval_trace", None)
+    if manager is None and trace is not None:
+        manager = ME.CoordinateManager.prepare(coords, trace)
+    if manager is not None:
+        st = ME.SparseTensor(features=feats, coordinates=coords, coordinate_manager=manager)
+    else:
+        st = ME.SparseTensor(coordinates=coords, features=feats)
+    out = model(st)
+    model._lidog_eval_trace = st.coordinate_manager.trace
     logits = (out[0] if isinstance(out, tuple) else out).F
     model.train(was_training)
     return logits.max(dim=1)[1], logits
+
+
+class Predictor:
+    """predict() over a stream of batches with the NEXT batch's coordinate maps built on the side stream while
+    the current forward pass runs: p = Predictor(model); preds, logits = p(coords, feats, next_coords)"""
+
+    def __init__(self, model):
+        self.model, self._next = model, None
+
+    def __call__(self, coords, feats, next_coords=None):
+        mgr = None
+        if self._next is not None and self._next[0] is coords:
+            mgr = self._next[1]
+        self._next = None
+        # the next batch's coordinates are valid NOW: its maps only wait for what is queued so far, not for the
+        # forward pass that is about to be launched
+        ready = torch.cuda.Event()
+        ready.record()
+        out = predict(self.model, coords, feats, mgr)
+        trace = getattr(self.model, "_lidog_eval_trace", None)
+        if next_coords is not None and trace is not None:
+            self._next = (next_coords, ME.CoordinateManager.prepare(next_coords, trace, ready))
+        return out
 
 
 @torch.no_grad()
@@ -48,9 +83,12 @@ def evaluate(model, batches, num_classes=7, ignore_label=-1):
     """batches: iterable of dicts with coords_int [N,4], source_features0, source_sem_labels0 (one IoU row per
     scan, as test_step is called with batch size 1 in eval_target.py)"""
     rows = []
-    for b in batches:
+    run = Predictor(model)
+    batches = list(batches)
+    for i, b in enumerate(batches):
         coords = b["coords_int"]
-        preds, _ = predict(model, coords, b["source_features0"])
+        nxt = batches[i + 1]["coords_int"] if i + 1 < len(batches) else None
+        preds, _ = run(coords, b["source_features0"], nxt)
         labels = b["source_sem_labels0"]
         for s in range(int(coords[:, 0].max().item()) + 1):
             sel = coords[:, 0] == s
