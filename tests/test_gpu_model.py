@@ -38,7 +38,14 @@ def test_minkunet34bev_matches_reference_golden():
     assert d0 <= 1e-4, f"eval-mode logits differ by {d0}"
     # mIoU parity (the paper's quality metric, trainer_lighting_bev.py:265-383) on the synthetic labels
     from lidog_amd.evaluate import per_class_iou, predict
-    preds, _ = predict(model, C, feats)
+    preds, lg0 = predict(model, C, feats)
+    # second call: maps built in one go from the recorded trace; Predictor: maps prepared ahead -- same logits
+    from lidog_amd.evaluate import Predictor
+    _, lg1 = predict(model, C, feats)
+    run = Predictor(model)
+    run(C, feats, C)
+    _, lg2 = run(C, feats)
+    assert torch.equal(lg0, lg1) and torch.equal(lg0, lg2) and torch.equal(lg0, sem0.F)
     ref_preds = torch.from_numpy(g5["eval_logits_initial"]).max(dim=1)[1]
     assert (preds.cpu() != ref_preds).float().mean().item() <= 1e-3   # only exact near-ties may flip
     iou_g = per_class_iou(preds, labels, 7, -1).cpu()
