@@ -104,6 +104,12 @@ int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int3
 /* count / eps / momentum / mean / invstd / running_*: as for lidog_bn_stats below (the last kernel of the
  * reduction also stores the row count behind the sums and, when mean != NULL, finalises the statistics). */
 
+/* Cin == 1 convolution (the 5^3 stem) straight from the neighbour table nbr [K][n] of lidog_kernel_map, no product
+ * rows: out[o] = sum_k x[nbr[k][o]] * W[k][:] (+ bias), bit-identical to lidog_sconv_gemm + lidog_sconv_reduce.
+ * Cout in {16, 32, 64}. */
+int lidog_sconv_cin1(const float *x, const int32_t *nbr, const float *W, const float *bias, int64_t n, int32_t K,
+                     int32_t C, float *out, void *stream);
+
 /* Output-stationary convolution for stride-1 odd kernels (csrc/sconv_os.hip): out = sum_k A[pair_in] . W[k] without
  * the product rows T and the reduction pass; bit-identical to lidog_sconv_gemm + lidog_sconv_reduce.
  * seg [K][ceil(n_out/256)+1] int32 from lidog_sconv_os_segments (first pair of every (offset, 256-row block)).

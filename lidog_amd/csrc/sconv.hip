@@ -401,6 +401,82 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__res
     }
 }
 
+// Cin == 1 (the 5^3 stem): no product rows at all.  out[o] = sum over k ascending of x[nbr[k][o]] * W[k][:] straight from
+// the neighbour table (a product row of the two-pass path is fmaf(x, w, 0) = x * w, added in the same order: same
+// bits).  One thread per output row (consecutive lanes read consecutive entries of a table row), all C4 <= 16
+// float4 accumulators in registers, weights broadcast from LDS.  Saves writing and re-reading P x Cout floats
+// (420 MB for the 125-offset stem at bs 4) and the [K, n] position table of the reduction.
+template <int C4>
+__global__ __launch_bounds__(256) void k_sconv_cin1(const float *__restrict__ x, const int32_t *__restrict__ nbr,
+                                                    const float4 *__restrict__ W, int64_t n, int K,
+                                                    const float4 *__restrict__ bias, float4 *__restrict__ out) {
+    extern __shared__ float4 s_w4[];  // [K][C4]
+    for (int e = threadIdx.x; e < K * C4; e += 256) s_w4[e] = W[e];
+    __syncthreads();
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    float4 acc[C4];
+#pragma unroll
+    for (int c = 0; c < C4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 5 <= K; k += 5) {   // five neighbours per round: index loads, then the gathers, then the adds
+        int idx[5];
+        float xv[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) idx[j] = nbr[(int64_t)(k + j) * n + o];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) xv[j] = x[idx[j] < 0 ? 0 : idx[j]];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (idx[j] < 0) continue;   // a missing neighbour adds an exact 0
+#pragma unroll
+            for (int c = 0; c < C4; ++c) {
+                const float4 w = s_w4[(k + j) * C4 + c];
+                acc[c].x += xv[j] * w.x;
+                acc[c].y += xv[j] * w.y;
+                acc[c].z += xv[j] * w.z;
+                acc[c].w += xv[j] * w.w;
+            }
+        }
+    }
+    for (; k < K; ++k) {
+        const int i = nbr[(int64_t)k * n + o];
+        if (i < 0) continue;
+        const float xv = x[i];
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            const float4 w = s_w4[k * C4 + c];
+            acc[c].x += xv * w.x;
+            acc[c].y += xv * w.y;
+            acc[c].z += xv * w.z;
+            acc[c].w += xv * w.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C4; ++c) {
+        if (bias) {
+            const float4 b = bias[c];
+            acc[c].x += b.x; acc[c].y += b.y; acc[c].z += b.z; acc[c].w += b.w;
+        }
+        out[o * C4 + c] = acc[c];
+    }
+}
+
+extern "C" int lidog_sconv_cin1(const float *x, const int32_t *nbr, const float *W, const float *bias, int64_t n,
+                                int32_t K, int32_t C, float *out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE((C == 16 || C == 32 || C == 64) && (int64_t)K * C * 4 <= 48 * 1024,
+                  "sconv_cin1: Cout must be 16, 32 or 64 with K*Cout*4 bytes of weights <= 48 KB");
+    if (n == 0) return 0;
+    const unsigned grid = (unsigned)cdiv64(n, 256);
+    const size_t lds = (size_t)K * C * sizeof(float);
+    if (C == 16) k_sconv_cin1<4><<<grid, 256, lds, st>>>(x, nbr, (const float4 *)W, n, K, (const float4 *)bias, (float4 *)out);
+    else if (C == 32) k_sconv_cin1<8><<<grid, 256, lds, st>>>(x, nbr, (const float4 *)W, n, K, (const float4 *)bias, (float4 *)out);
+    else k_sconv_cin1<16><<<grid, 256, lds, st>>>(x, nbr, (const float4 *)W, n, K, (const float4 *)bias, (float4 *)out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C) {
     // doubles of workspace needed by lidog_sconv_reduce_stats
     (void)n;

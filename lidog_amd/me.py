@@ -616,6 +616,10 @@ class _SparseConvFn(torch.autograd.Function):
             _gemm(x, None, W3, bias, m, Cin, Cout, out, None)
         elif single_out:
             _gemm(x, g_in, W3, bias, m, Cin, Cout, out, g_out)
+        elif Cin == 1 and not swap and Cout in (16, 32, 64) and K * Cout * 4 <= 48 * 1024 and m.nbr is not None:
+            # the stem: straight from the neighbour table, no product rows (bit-identical to the two-pass path); the
+            # BatchNorm statistics of its 32-channel output are then one small pass of their own
+            call("lidog_sconv_cin1", ptr(x), ptr(m.nbr), ptr(W3), ptr(bias), n_out, K, Cout, ptr(out))
         else:
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
             _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
