@@ -232,6 +232,45 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_cout8(const float *__restric
     }
 }
 
+// Cin <= 8, Cout % 4 == 0 (the classifier's data gradient, 7 -> 96): thread (row, column quad); the row's <= 8
+// inputs and the weights (LDS) give four outputs by the same ascending-ci fmaf chain as the other cores
+__global__ __launch_bounds__(256) void k_sconv_gemm_cin8(const float *__restrict__ A,
+                                                         const int32_t *__restrict__ gather,
+                                                         const float *__restrict__ B,
+                                                         const float *__restrict__ bias,
+                                                         const int32_t *__restrict__ tile_k,
+                                                         const int32_t *__restrict__ tile_row0,
+                                                         const int32_t *__restrict__ tile_rows, int Cin, int Cout,
+                                                         float *__restrict__ T,
+                                                         const int32_t *__restrict__ scatter) {
+    extern __shared__ float s_w[];  // [Cin][Cout]
+    const int tile = blockIdx.x;
+    const int k = tile_k[tile], row0 = tile_row0[tile], rows = tile_rows[tile];
+    const float *Bk = B + (size_t)k * Cin * Cout;
+    for (int e = threadIdx.x; e < Cin * Cout; e += 256) s_w[e] = Bk[e];
+    __syncthreads();
+    const int C4 = Cout / 4;
+    for (int e = threadIdx.x; e < rows * C4; e += 256) {
+        const int r = e / C4, c4 = e - r * C4;
+        const int src = gather ? gather[row0 + r] : (row0 + r);
+        const float *x = A + (size_t)src * Cin;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = x[ci];
+            const float4 w = *reinterpret_cast<const float4 *>(&s_w[ci * Cout + c4 * 4]);
+            t.x = __builtin_fmaf(xv, w.x, t.x);
+            t.y = __builtin_fmaf(xv, w.y, t.y);
+            t.z = __builtin_fmaf(xv, w.z, t.z);
+            t.w = __builtin_fmaf(xv, w.w, t.w);
+        }
+        if (bias) {
+            t.x += bias[c4 * 4]; t.y += bias[c4 * 4 + 1]; t.z += bias[c4 * 4 + 2]; t.w += bias[c4 * 4 + 3];
+        }
+        const size_t dst = scatter ? (size_t)scatter[row0 + r] : (size_t)(row0 + r);
+        *reinterpret_cast<float4 *>(&T[dst * Cout + c4 * 4]) = t;
+    }
+}
+
 extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
                                 const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows,
                                 int32_t n_tiles, int32_t Cin, int32_t Cout, float *T, const int32_t *scatter,
@@ -260,7 +299,10 @@ extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const flo
         case 4: LAUNCH_GEMM(4); break;
         case 2: LAUNCH_GEMM(2); break;
         default:
-            if (Cout <= 8 && Cin % 4 == 0 && Cin <= 1024)
+            if (Cin <= 8 && Cout % 4 == 0 && Cin * Cout * 4 <= 32 * 1024)
+                k_sconv_gemm_cin8<<<dim3((unsigned)n_tiles), 256, (size_t)Cin * Cout * sizeof(float), st>>>(
+                    A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter);
+            else if (Cout <= 8 && Cin % 4 == 0 && Cin <= 1024)
                 k_sconv_gemm_cout8<<<dim3((unsigned)n_tiles), 256, (size_t)Cin * 8 * sizeof(float), st>>>(
                     A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter);
             else
