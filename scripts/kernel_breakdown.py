@@ -6,7 +6,7 @@ import collections, sqlite3, sys
 db, steps = sys.argv[1], int(sys.argv[2])
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, stream_id from kernels order by start").fetchall()
-CATS = [("gathered GEMM (sconv fwd/dgrad)", ("k_sconv_gemm",)), ("sparse wgrad", ("k_sconv_wgrad", "k_items_sum")),
+CATS = [("gathered GEMM (sconv fwd/dgrad)", ("k_sconv_gemm", "k_sconv_cin1<")), ("sparse wgrad", ("k_sconv_wgrad", "k_items_sum")),
         ("per-row reduction", ("k_sconv_reduce",)), ("conv2d (BEV head)", ("k_conv_", "k_pw_", "k_repack", "k_sum_splits", "k_sum_group", "k_support", "k_tile_lists", "k_group_lists")),
         ("BatchNorm / ReLU / add", ("k_colreduce", "k_sums_", "k_bn_", "k_partials", "k_stats_finish", "k_relu", "k_add")),
         ("coordinate + kernel maps", ("k_kernel_map", "k_pairs", "k_insert", "k_first_row", "k_stride", "scan_", "k_compact")),
