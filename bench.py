@@ -27,13 +27,14 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak = vector fp32 peak (MI355X_MICROARCH.md, Matrix cores)
+PMC_TRAFFIC_FILE = "r02_pmc_traffic_gemm.json"   # scripts/profile_round.sh writes it (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="scans per GPU (configs[1]: bs=4)")
     ap.add_argument("--config", default="kitti120k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,7 +116,8 @@ def cpu_baseline(config, steps_budget_s=30.0, threads=None):
     dt = time.time() - t0
     OME.set_mode("exact")
     torch.set_num_threads(prev_threads)
-    return {"value": n / dt, "unit": "scans/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "scans/s", "cores": threads, "host_cpu_count": os.cpu_count(),
+            "torch_num_threads": threads, "kind": "port",
             "sample": f"{n} training step(s) of 1 synthetic {config} scan, MinkUNet34BEV B=50, oracle blas mode "
                       f"(per-offset gather->GEMM->scatter-add), {dt:.1f} s"}
 
@@ -140,7 +142,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29512")
+            if "MASTER_PORT" not in os.environ:   # the launcher's rendezvous port is the only source for N > 1
+                assert single_dp, "MASTER_PORT must come from the launcher (torch.distributed.run)"
+                import socket
+                with socket.socket() as sk:       # one-rank group on a 1-GPU box: any free port
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -168,6 +175,11 @@ def main():
     batches = [synth.make_batch(range(base + i * args.batch, base + (i + 1) * args.batch), args.config, "cuda")
                for i in range(2)]
     n_vox = sum(b["coords_int"].shape[0] for b in batches) / (2 * args.batch)
+    # the workload is BASELINE.md's: scan seed 0 must have SURVEY.md 8(d)'s per-stride voxel counts
+    seed0_counts = None
+    if args.config in synth.BASELINE_COUNTS:
+        seed0_counts = list(synth.stride_counts(synth.scan_voxels(0, args.config)[0]))
+        assert tuple(seed0_counts) == synth.BASELINE_COUNTS[args.config], (seed0_counts, synth.BASELINE_COUNTS[args.config])
 
     def sync():
         if world > 1 or single_dp:
@@ -237,9 +249,10 @@ def main():
         res = {"metric": "LiDAR scans/sec, MinkUNet34+BEV training step @120k pts", "value": value, "unit": "scans/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"train_lidog.py Synth4D-kitti-like MinkUNet34 + BEV head (B=50 m, 0.05 m voxels), "
-                                      f"bs={args.batch}/GPU, {args.config} synthetic scans, "
-                                      f"{n_vox:.0f} voxels/scan, SoftDICE+DICE, Adam", "global_batch": world * args.batch,
+               "config": {"workload": f"{n_vox:.0f} voxels/scan ({args.config} synthetic, 0.05 m), MinkUNet34+BEV B=50 "
+                                      f"train step (configs[1]), bs={args.batch}/GPU, SoftDICE+DICE, Adam",
+                          "voxels_per_scan": n_vox, "seed0_stride_counts": seed0_counts,
+                          "global_batch": world * args.batch,
                           "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else "")},
                "loss": loss}
         if eval_rate is not None:
@@ -251,7 +264,7 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes over this same command
             # (scripts/pmc_traffic.py, FETCH_SIZE doubled per MI355X_MICROARCH.md); None if not collected
             traffic = None
-            pmc = os.path.join(REPO, "profiles", "pmc_traffic_gemm.json")
+            pmc = os.path.join(REPO, "profiles", PMC_TRAFFIC_FILE)
             if os.path.exists(pmc) and args.config == "kitti120k" and args.batch == 4:
                 traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
             # The dominant kernel is an exact-f32 MFMA GEMM: its binding roofline is the fp32 matrix rate
@@ -259,6 +272,8 @@ def main():
             # next to it (algorithmic bytes / launch time against 8 TB/s, and the PMC-measured traffic).
             res["roofline"] = {"bound": "mfma", "achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tfl / FP32_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc passes of this build, "
+                                                 "not collected by this run)" if traffic is not None else None,
                                "kernel": "k_sconv_gemm_mfma (gathered GEMM of the sparse convolutions, f32 MFMA)",
                                "algorithmic_flops_per_launch": s["flops"] / s["launches"],
                                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],

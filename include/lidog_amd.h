@@ -277,6 +277,24 @@ int lidog_bev_label_raster(const int32_t *coords, const int32_t *labels, int64_t
 int lidog_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                     void *stream);
+/* torch.optim.SGD(lr, momentum=0.98, weight_decay, nesterov=True) of trainer_lighting_2d.py:351-355 (and
+ * trainer_lighting.py:337-341) on a slice of the flat buffers; momentum_buf starts at zero. */
+int lidog_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t n, float lr, float momentum,
+                   float weight_decay, int32_t nesterov, float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------ collectives (RCCL over xGMI)
+ * The two collectives of the data-parallel path for hosts that do not go through torch.distributed: the gradient
+ * all-reduce of Lightning DDP (train_lidog.py:227-231, strategy='ddp'; sum, the caller folds 1/world into the
+ * optimiser step) and the SyncBatchNorm statistics all-reduce (ME.MinkowskiSyncBatchNorm, train_lidog.py:228; the
+ * (sum, sum, rows) vectors of lidog_bn_stats / lidog_bn_bwd_reduce are fp64).  librccl is loaded at first use.
+ * One process per GPU: rank 0 calls lidog_comm_unique_id and ships the bytes to the others (any host channel),
+ * every rank calls lidog_comm_init_rank with its device current.  In place, asynchronous on `stream`. */
+int32_t lidog_comm_unique_id_bytes(void);
+int lidog_comm_unique_id(void *id_out);
+int lidog_comm_init_rank(const void *id, int32_t nranks, int32_t rank, void **comm_out);
+int lidog_comm_destroy(void *comm);
+int lidog_allreduce_f32(float *buf, int64_t n, void *comm, void *stream);
+int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *stream);
 
 #ifdef __cplusplus
 }

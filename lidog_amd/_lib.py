@@ -63,6 +63,13 @@ SIGNATURES = {
     "lidog_dice_fwd": [_p, _p, _i64, _i32, _i64, _i32, _f, _i32, _i32, _i32, _f, _p, _p, _p, _p],
     "lidog_dice_bwd": [_p, _p, _i64, _i32, _i64, _i32, _f, _i32, _i32, _p, _p, _p, _p],
     "lidog_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i32, _f, _p],
+    "lidog_sgd_step": [_p, _p, _p, _i64, _f, _f, _f, _i32, _f, _p],
+    "lidog_comm_unique_id_bytes": [],
+    "lidog_comm_unique_id": [_p],
+    "lidog_comm_init_rank": [_p, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)],
+    "lidog_comm_destroy": [_p],
+    "lidog_allreduce_f32": [_p, _i64, _p, _p],
+    "lidog_allreduce_f64": [_p, _i64, _p, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
              "lidog_dice_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}

@@ -20,10 +20,37 @@ def load_lightning_checkpoint(model, path, strict=True, map_location="cpu"):
     return ckpt.get("epoch"), missing
 
 
-def save_lightning_checkpoint(model, path, epoch=0, global_step=0, optimizer=None):
-    """writes the keys eval_target.py / --auto_resume of the reference read back"""
+def _cpu(v):
+    if torch.is_tensor(v):
+        return v.detach().cpu()
+    if isinstance(v, dict):
+        return {k: _cpu(x) for k, x in v.items()}
+    return v
+
+
+def save_lightning_checkpoint(model, path, epoch=0, global_step=0, optimizer=None, scheduler=None):
+    """writes the keys eval_target.py / --auto_resume of the reference read back (`epoch`, `global_step`,
+    `state_dict` with the `model.` prefix) plus Lightning's `optimizer_states` / `lr_schedulers` lists, which
+    load_training_checkpoint uses to resume (trainer.fit(ckpt_path=...), train_lidog.py:298-301)"""
     ckpt = {"epoch": epoch, "global_step": global_step,
             "state_dict": {"model." + k: v.detach().cpu() for k, v in model.state_dict().items()}}
     if optimizer is not None:
-        ckpt["optimizer_states"] = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in optimizer.state_dict().items()}]
-    torch.save(ckpt, path)
+        ckpt["optimizer_states"] = [_cpu(optimizer.state_dict())]
+    if scheduler is not None:
+        ckpt["lr_schedulers"] = [scheduler.state_dict()]
+    tmp = path + ".tmp"
+    torch.save(ckpt, tmp)
+    import os
+    os.replace(tmp, path)     # a killed run never leaves a truncated checkpoint behind for --auto_resume
+
+
+def load_training_checkpoint(model, path, optimizer=None, scheduler=None, map_location="cpu"):
+    """model + optimiser state + scheduler position of a checkpoint written by save_lightning_checkpoint; returns the
+    checkpoint dict (`epoch` = the epoch that had FINISHED when it was written: training resumes at epoch + 1)"""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(model_state_dict(ckpt), strict=True)
+    if optimizer is not None and ckpt.get("optimizer_states"):
+        optimizer.load_state_dict(ckpt["optimizer_states"][0])
+    if scheduler is not None and ckpt.get("lr_schedulers"):
+        scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+    return ckpt

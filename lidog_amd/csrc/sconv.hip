@@ -532,7 +532,8 @@ extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int6
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconv_reduce_stats: C must be a multiple of 4, <= 1024");
     LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_reduce_stats: finalising needs the row count");
-    if (n == 0) return 0;
+    // no rows (a rank whose shard is empty): the sums a SyncBatchNorm all-reduce will add must be zeros, not garbage
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     int C4 = C / 4, RB = 256 / C4;
     int64_t nb = cdiv64(n, (int64_t)RB * 4);
     if (nb > 2048) nb = 2048;

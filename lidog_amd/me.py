@@ -417,7 +417,9 @@ class CoordinateManager:
 
 class SparseTensor:
     def __init__(self, features=None, coordinates=None, coordinate_manager=None, coordinate_map_key=None,
-                 tensor_stride=1, **_unused):
+                 tensor_stride=1, **unsupported):
+        if unsupported:   # e.g. quantization_mode, minkowski_algorithm: not part of the LiDOG hot path
+            raise TypeError(f"lidog_amd.me.SparseTensor: unsupported arguments {sorted(unsupported)}")
         if coordinate_manager is None:
             if coordinates is None:
                 raise ValueError("SparseTensor needs coordinates or a coordinate manager")
@@ -431,14 +433,22 @@ class SparseTensor:
             if uniq is not None:
                 features = features[uniq.long()]
             coordinate_map_key = 1
-        elif coordinate_manager._ready is not None:
-            # built ahead of time by CoordinateManager.prepare(coordinates, trace) on the side stream
+        else:
+            # a manager prepared ahead of time (CoordinateManager.prepare) is handed to this stream on first use
             coordinate_manager.handover()
-            if coordinate_map_key is None and coordinate_manager.uniq is not None:
-                features = features[coordinate_manager.uniq.long()]
+            if coordinates is not None and coordinate_map_key is None:
+                # input tensor of a prepared manager: duplicates were dropped when the map was built, so the same
+                # rows are dropped from EVERY feature matrix that enters with these coordinates (also on a second
+                # forward pass over the same batch)
+                if coordinate_manager.uniq is not None:
+                    features = features[coordinate_manager.uniq.long()]
                 coordinate_map_key = 1
         self.coordinate_manager = coordinate_manager
         self.coordinate_map_key = coordinate_map_key if coordinate_map_key is not None else tensor_stride
+        if features is not None and self.coordinate_map_key in coordinate_manager.maps and \
+                features.shape[0] != coordinate_manager.maps[self.coordinate_map_key].n:
+            raise ValueError(f"{features.shape[0]} feature rows on a coordinate map of "
+                             f"{coordinate_manager.maps[self.coordinate_map_key].n} rows")
         self._F = features
 
     F = property(lambda self: self._F)
@@ -507,13 +517,25 @@ class _ReLUFn(torch.autograd.Function):
 
 
 def _grad_out(param, shape):
-    """Fresh view into the optimiser's flat gradient buffer for `param` (lidog_amd.trainer.FlatParams), or None.
+    """Fresh view into the optimiser's flat gradient buffer for `param` (lidog_amd.optim.FlatParams), or None.
     A backward kernel that writes its parameter gradient there and returns the view lets autograd adopt it as
-    param.grad without the `grad += new` pass (one extra kernel per parameter per step otherwise)."""
+    param.grad without the `grad += new` pass (one extra kernel per parameter per step otherwise).
+    The slice is handed out at most ONCE per parameter and backward pass (generation counter of FlatParams,
+    advanced by zero_grad): when a parameter is used by two autograd nodes of one graph -- the reference's
+    multi-source pipelines call the model twice before one backward (trainer_lighting_2d_multi.py:166-167) -- the
+    second node gets None, computes into a fresh tensor, and autograd ACCUMULATES it into the view.  Before that
+    second node runs, the main stream joins the weight-gradient lane: the first node's kernel may still be writing
+    the slice there."""
     ref = getattr(param, "_flat_ref", None)
     if ref is None or param.grad is not None:
         return None
-    buf, off = ref
+    buf, off, owner = ref
+    if param._flat_taken == owner.generation:
+        lane = wgrad_lane(buf.device) if buf.is_cuda else None
+        if lane is not None:
+            torch.cuda.current_stream(buf.device).wait_stream(lane.stream)
+        return None
+    param._flat_taken = owner.generation
     return buf[off:off + param.numel()].view(shape)
 
 
@@ -730,9 +752,9 @@ class StatsRequest:
     epilogue of its reduction pass (conv_bn), and where it leaves them."""
     __slots__ = ("eps", "momentum", "running_mean", "running_var", "sync", "sums", "mean", "invstd")
 
-    def __init__(self, bn, sync):
+    def __init__(self, bn, sync, momentum):
         self.eps = float(bn.eps)
-        self.momentum = 0.0 if bn.momentum is None else float(bn.momentum)
+        self.momentum = float(momentum)
         self.running_mean, self.running_var = bn.running_mean, bn.running_var
         self.sync = sync
         self.sums = self.mean = self.invstd = None
@@ -839,16 +861,28 @@ def _count_batch(bn):
         bn.register_load_state_dict_pre_hook(lambda module, *_: setattr(module, "_nbt_pending", 0))
 
 
+def _training_momentum(bn):
+    """running-statistics update factor of ONE training-mode forward pass, counting the batch as torch does:
+    bn.momentum, or 1 / num_batches_tracked (cumulative moving average) when bn.momentum is None"""
+    if not (bn.track_running_stats and bn.num_batches_tracked is not None):
+        return 0.0 if bn.momentum is None else float(bn.momentum)
+    if bn.momentum is None:   # the factor depends on the counter: read it (one host synchronisation; no LiDOG config
+        _flush_batch_counter(bn)                       # uses momentum=None, MinkowskiBatchNorm defaults to 0.1)
+        count = int(bn.num_batches_tracked.item()) + 1
+        bn.num_batches_tracked.add_(1)
+        return 1.0 / count
+    _count_batch(bn)
+    return float(bn.momentum)
+
+
 def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, stats=None):
     """functional entry used by the modules below and by lidog_amd.bev; `stats`: the StatsRequest a convolution
-    has filled (conv_bn), or None"""
+    has filled (conv_bn; the batch is then already counted), or None"""
     training = bn.training or not bn.track_running_stats
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        if bn.momentum is None:  # cumulative average reads the counter: keep it exact on the device
-            bn.num_batches_tracked.add_(1)
-        else:
-            _count_batch(bn)
-    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if stats is not None:
+        momentum = stats.momentum
+    else:
+        momentum = _training_momentum(bn) if training else 0.0
     pre = (stats.sums, stats.mean, stats.invstd) if (training and stats is not None and stats.sums is not None) else None
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                               hw, relu, residual, group, pre)
@@ -983,7 +1017,7 @@ def conv_bn(conv, bn_module, x, relu=False, residual=None, skip=False):
     bn = bn_module.bn
     req = None
     if bn.training or not bn.track_running_stats:
-        req = StatsRequest(bn, bn_module._sync_group() is not None)
+        req = StatsRequest(bn, bn_module._sync_group() is not None, _training_momentum(bn))
     if skip:
         y, x_alias = conv(x, stats=req, skip=True)
         return bn_module(y, relu=relu, residual=residual, stats=req), x_alias
@@ -1040,7 +1074,55 @@ class SparseCollation:
                 torch.cat([torch.as_tensor(l) for l in labels], dim=0))
 
 
+def sparse_quantize(coordinates, features=None, labels=None, ignore_label=-100, return_index=False,
+                    return_inverse=False, return_maps_only=False, quantization_size=None, device="cuda"):
+    """ME.utils.sparse_quantize with MinkowskiEngine 0.5.4's signature and return convention, as the reference
+    calls it: utils/datasets/semantickitti_bev.py:232-238 (5 results), utils/datasets/mix3D.py:67-72 (4),
+    utils/models/minkunet_bev.py:279-284 (3, vector quantization_size).  numpy arrays in -> numpy arrays out, torch
+    tensors in -> torch tensors on the input's device out; the work (floor-divide, hash unique, label vote) runs in
+    the HIP kernels of lidog_amd.data.sparse_quantize -- there is no CPU implementation, so a DataLoader worker that
+    calls this needs the GPU (start method 'spawn'), see INTEGRATION.md."""
+    from . import data as _data
+    is_np = isinstance(coordinates, np.ndarray)
+
+    def to_dev(a):
+        if a is None:
+            return None
+        return (torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a).to(device)
+
+    def back(t, like):
+        if is_np:
+            return t.cpu().numpy()
+        return t.to(like.device)
+
+    pts = to_dev(coordinates).float()
+    q = 1 if quantization_size is None else quantization_size
+    if torch.is_tensor(q):
+        q = q.cpu().numpy()
+    res = _data.sparse_quantize(pts, None, labels=to_dev(labels), ignore_label=ignore_label, quantization_size=q,
+                                return_index=True, return_inverse=True)
+    if labels is not None:
+        coords, vlab, index, inverse = res
+    else:
+        (coords, index, inverse), vlab = res, None
+    if return_maps_only:
+        out = [back(index, coordinates)] + ([back(inverse, coordinates)] if return_inverse else [])
+        return out[0] if len(out) == 1 else tuple(out)
+    out = [back(coords, coordinates)]
+    if features is not None:
+        idx_host = index.cpu().numpy() if isinstance(features, np.ndarray) else index.to(features.device)
+        out.append(features[idx_host])
+    if labels is not None:
+        out.append(back(vlab, labels))
+    if return_index:
+        out.append(back(index, coordinates))
+    if return_inverse:
+        out.append(back(inverse, coordinates))
+    return out[0] if len(out) == 1 else tuple(out)
+
+
 utils = types.ModuleType(__name__ + ".utils")
+utils.sparse_quantize = sparse_quantize
 utils.kaiming_normal_ = kaiming_normal_
 utils.SparseCollation = SparseCollation
 utils.batched_coordinates = batched_coordinates

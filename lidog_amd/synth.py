@@ -21,7 +21,10 @@ CONFIGS = {
 def scan_points(seed, n_beams, n_az, elev, h, **_):
     rng = np.random.default_rng(seed)
     el = np.deg2rad(np.linspace(elev[0], elev[1], n_beams))
-    az = np.sort(rng.uniform(0.0, 2 * np.pi, n_az))
+    # evenly spaced azimuths (a spinning sensor fires at a fixed angular step): this is the generator behind the
+    # per-stride voxel counts of SURVEY.md 8(d) / BASELINE.md (seed 0, kitti120k: 88 117 / 51 939 / 25 521 / 10 354 /
+    # 3 777), asserted by tests/test_oracle_cpu.py::test_synth_matches_baseline_counts and by bench.py
+    az = np.linspace(0.0, 2 * np.pi, n_az, endpoint=False)
     wall = rng.uniform(5.0, 50.0, 64)
     EL, AZ = np.meshgrid(el, az, indexing="ij")
     sector = np.minimum((AZ / (2 * np.pi) * 64).astype(np.int64), 63)
@@ -42,6 +45,20 @@ def voxelize(pts, voxel, lidog_bounds):
     vox = np.floor(pts / np.float32(voxel)).astype(np.int32)
     _, first = np.unique(vox, axis=0, return_index=True)
     return vox[np.sort(first)]
+
+
+# voxels per tensor stride 1/2/4/8/16 of scan seed 0
+BASELINE_COUNTS = {
+    "kitti120k": (88117, 51939, 25521, 10354, 3777),
+    "source8k": (6948, 5033, 3205, 1691, 763),
+    "highres524k": (460962, 302486, 144935, 58803, 20581),
+    "nusc35k+mix3d": (51943, 37745, 25811, 14387, 6939),
+}
+
+
+def stride_counts(vox):
+    """voxels at tensor stride 1, 2, 4, 8, 16 (floor division, as the strided coordinate maps)"""
+    return (len(vox),) + tuple(len(np.unique(np.floor_divide(vox, s), axis=0)) for s in (2, 4, 8, 16))
 
 
 def scan_voxels(seed, config="kitti120k"):

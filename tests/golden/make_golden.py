@@ -161,6 +161,14 @@ def _kmap_fingerprints(cm):
     return fp
 
 
+G5_GRAD_VECTORS = ["conv1p1s2.kernel", "block1.0.conv1.kernel", "block1.1.norm2.bn.weight", "conv2p2s2.kernel",
+                   "block2.0.downsample.0.kernel", "block2.2.conv2.kernel", "conv3p4s2.kernel", "block3.0.norm1.bn.bias",
+                   "block3.0.downsample.0.kernel", "conv4p8s2.kernel", "block4.0.downsample.0.kernel",
+                   "block4.5.norm2.bn.weight", "bntr4.bn.weight", "block5.0.downsample.0.kernel", "convtr6p4s2.kernel",
+                   "block7.0.downsample.0.kernel", "convtr7p2s2.kernel", "block8.1.conv2.kernel",
+                   "encoders2d.block8.out_conv.conv.weight"]
+
+
 def g5_full_model():
     C = small_batch((0, 1))
     N = C.shape[0]
@@ -203,6 +211,13 @@ def g5_full_model():
             out["grad/final.bias"] = model.final.bias.grad.numpy()
             out["grad/conv0p1s1.kernel"] = model.conv0p1s1.kernel.grad.numpy()
             out["grad/bn0.bn.weight"] = model.bn0.bn.weight.grad.numpy()
+            # full gradient VECTORS of parameters spread over the depth of the network (cosine test of the whole
+            # backward chain), normalised to max |g| = 1 and stored as float16 (relative 5e-4 per element)
+            for n in G5_GRAD_VECTORS:
+                gvec = dict(model.named_parameters())[n].grad.numpy()
+                scale = float(np.abs(gvec).max())
+                out[f"grad16/{n}"] = (gvec / scale).astype(np.float16)
+                out[f"grad16scale/{n}"] = np.float32(scale)
             out["bn0_running_mean"] = model.bn0.bn.running_mean.numpy().copy()
             out["bn0_running_var"] = model.bn0.bn.running_var.numpy().copy()
         losses.append([float(l_sem), float(l_bev), float(total)])

@@ -37,6 +37,14 @@ def _worker(rank, world, port, q):
         dist.all_reduce(ref)
         assert torch.allclose(flat.grad, ref, rtol=1e-6, atol=1e-7), (flat.grad - ref).abs().max()
     idx = shard_indices(11, rank, world)
+    # DDP's start-up broadcast: ranks that seeded differently end up with rank 0's parameters
+    from lidog_amd.optim import _FlatOptimizer
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Linear(8, 8)
+    opt = _FlatOptimizer(net, 1e-3)
+    mine = opt.flat.flat.clone()
+    dist.broadcast(mine, src=0)
+    assert torch.equal(mine, opt.flat.flat) and net.weight.data_ptr() == opt.flat.flat.data_ptr()
     q.put((rank, idx))
     dist.destroy_process_group()
 
@@ -52,4 +60,5 @@ def test_gradient_buckets_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert got[0] == [0, 2, 4, 6, 8] and got[1] == [1, 3, 5, 7, 9]  # strided, equal length per rank
+    # DistributedSampler semantics: strided, padded by wrap-around so that both ranks get the same count
+    assert got[0] == [0, 2, 4, 6, 8, 10] and got[1] == [1, 3, 5, 7, 9, 0]

@@ -32,6 +32,34 @@ def test_sparse_quantize_matches_oracle(q):
     assert torch.equal(only, got[0])
 
 
+def test_me_utils_sparse_quantize_has_minkowski_engine_call_shapes():
+    """the zero-edit alias route: ME.utils.sparse_quantize as the reference calls it -- numpy in / numpy out with 5
+    results (semantickitti_bev.py:232-238), 4 (mix3D.py:67-72), 3 with a vector quantization_size
+    (minkunet_bev.py:279-284), CPU tensors in / CPU tensors out -- equal to the oracle's"""
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    pts, rng = synth.scan_points(5, **synth.CONFIGS["source8k"])
+    pts = np.concatenate([pts, pts[:300] + np.float32(0.004)])
+    labels = rng.integers(-1, 7, pts.shape[0])
+    feats = np.ones((pts.shape[0], 1), np.float32)
+    calls = [dict(args=(pts, feats), kw=dict(labels=labels, ignore_label=-1, quantization_size=0.05, return_index=True,
+                                             return_inverse=True), n=5),
+             dict(args=(pts, feats), kw=dict(labels=labels, ignore_label=-1, quantization_size=0.05, return_index=True), n=4),
+             dict(args=(pts,), kw=dict(quantization_size=[3.0, 2.0, 19.0], return_index=True, return_inverse=True), n=3)]
+    for c in calls:
+        ref = OME.utils.sparse_quantize(*c["args"], **c["kw"])
+        got = ME.utils.sparse_quantize(*c["args"], **c["kw"])
+        assert len(got) == len(ref) == c["n"]
+        for r, g in zip(ref, got):
+            assert isinstance(g, np.ndarray) and g.dtype == np.asarray(r).dtype and np.array_equal(np.asarray(r), g)
+    t = ME.utils.sparse_quantize(torch.from_numpy(pts), quantization_size=0.1, return_index=True)
+    r = OME.utils.sparse_quantize(torch.from_numpy(pts), quantization_size=0.1, return_index=True)
+    assert all(torch.is_tensor(a) and a.device.type == "cpu" and torch.equal(a, b) for a, b in zip(t, r))
+    maps = ME.utils.sparse_quantize(pts, quantization_size=0.05, return_maps_only=True, return_inverse=True)
+    assert np.array_equal(maps[0], OME.utils.sparse_quantize(pts, quantization_size=0.05, return_maps_only=True))
+
+
 def test_collate_matches_sparse_collation():
     import oracle.me_cpu as OME
     from lidog_amd.data import collate

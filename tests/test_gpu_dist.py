@@ -101,3 +101,39 @@ def test_single_rank_rccl_runs_every_data_parallel_path():
     dp = _bench_line({"LIDOG_BENCH_SINGLE_RANK_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     assert dp["config"]["parallelism"] == "dp1+syncbn" and plain["config"]["parallelism"] == "dp1"
     assert abs(dp["loss"] - plain["loss"]) <= 2e-5 * abs(plain["loss"]), (dp["loss"], plain["loss"])
+
+
+def _rccl_c_abi_worker(q):
+    """own process: RCCL initialised through the C ABI only (no torch.distributed)"""
+    import ctypes
+    sys.path.insert(0, REPO)
+    torch.cuda.set_device(0)
+    from lidog_amd import _lib
+    L = _lib.load()
+    nbytes = L.lidog_comm_unique_id_bytes()
+    uid = ctypes.create_string_buffer(nbytes)
+    assert L.lidog_comm_unique_id(uid) == 0, L.lidog_last_error()
+    comm = ctypes.c_void_p()
+    assert L.lidog_comm_init_rank(uid, 1, 0, ctypes.byref(comm)) == 0, L.lidog_last_error()
+    x = torch.randn(1 << 20, device="cuda")
+    s = torch.randn(193, device="cuda", dtype=torch.float64)
+    x0, s0 = x.clone(), s.clone()
+    _lib.call("lidog_allreduce_f32", _lib.ptr(x), x.numel(), comm)
+    _lib.call("lidog_allreduce_f64", _lib.ptr(s), s.numel(), comm)
+    torch.cuda.synchronize()
+    ok = torch.equal(x, x0) and torch.equal(s, s0)          # one rank: the sum is the identity
+    bad = L.lidog_comm_init_rank(uid, 1, 3, ctypes.byref(ctypes.c_void_p()))
+    ok = ok and bad != 0 and b"bad rank" in L.lidog_last_error()
+    assert L.lidog_comm_destroy(comm) == 0
+    q.put(bool(ok))
+
+
+def test_rccl_collectives_through_the_c_abi():
+    """lidog_comm_* / lidog_allreduce_f32 / _f64 (include/lidog_amd.h) against the real RCCL library, one rank"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_c_abi_worker, args=(q,))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0 and ok

@@ -95,6 +95,19 @@ def test_minkunet34bev_matches_reference_golden():
                 got = dict(model.named_parameters())[n].grad.cpu()
                 ref = torch.from_numpy(g5[f"grad/{n}"])
                 assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-9, n
+            # full-chain check on gradient VECTORS of parameters spread over the depth (golden: float16, max-normalised)
+            named = dict(model.named_parameters())
+            vec_names = [k[len("grad16/"):] for k in g5.files if k.startswith("grad16/")]
+            assert len(vec_names) >= 10
+            cos = {}
+            for n in vec_names:
+                ref = torch.from_numpy(g5[f"grad16/{n}"].astype(np.float32)).flatten().double() * float(g5[f"grad16scale/{n}"])
+                got = named[n].grad.detach().cpu().flatten().double()
+                cos[n] = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
+                nr = float(got.norm() / ref.norm())
+                assert abs(nr - 1) <= 2e-2, (n, nr)
+            worst = min(cos, key=cos.get)
+            assert cos[worst] >= 1 - 1e-4, (worst, cos[worst], cos)
             for n in ("conv0p1s1.kernel", "bn0.bn.weight"):
                 got = dict(model.named_parameters())[n].grad.cpu()
                 ref = torch.from_numpy(g5[f"grad/{n}"])
@@ -115,8 +128,14 @@ def test_minkunet34bev_matches_reference_golden():
         sem, none = model(ME.SparseTensor(coordinates=C, features=feats), is_train=False)
     assert none is None
     d = (sem.F.cpu() - torch.from_numpy(g5["eval_logits_after3"])).abs().max().item()
-    # three sign-like Adam updates in, the two trajectories have separated (see above): sanity bound only
-    assert d <= 0.5, f"eval logits (running statistics, 3 Adam steps in) differ by {d}"
+    # Three sign-like Adam updates in, the two trajectories have separated (see above), so this is measured against
+    # how far the reference itself moved over those steps: the validation logits must have followed the reference's
+    # movement (weights AND running statistics updated), to within a fraction of it on average.
+    ref0, ref3 = torch.from_numpy(g5["eval_logits_initial"]), torch.from_numpy(g5["eval_logits_after3"])
+    move = (ref3 - ref0).abs().mean().item()
+    err = (sem.F.cpu() - ref3).abs().mean().item()
+    stay = (sem.F.cpu() - ref0).abs().mean().item()
+    assert move > 1e-3 and err <= 0.1 * move and stay >= 0.5 * move, (move, err, stay, d)
 
 
 def test_minkunet34_matches_reference_golden():

@@ -273,6 +273,10 @@ def test_reference_model_file_builds_on_product_api():
         "import sys; sys.dont_write_bytecode = True; sys.path.insert(0, %r); sys.path.insert(1, '/root/reference');"
         "import lidog_amd.me as ME; ME.install_as_minkowski_engine();"
         "from utils.models.minkunet_bev import MinkUNet34BEV as Ref; import lidog_amd;"
+        "import inspect, MinkowskiEngine as M;"
+        "sig = inspect.signature(M.utils.sparse_quantize).parameters;"
+        "assert list(sig)[:4] == ['coordinates', 'features', 'labels', 'ignore_label'] and "
+        "{'return_index', 'return_inverse', 'quantization_size'} <= set(sig);"
         "r = Ref(in_channels=1, out_channels=7, D=3); m = lidog_amd.MinkUNet34BEV(1, 7, 3);"
         "assert list(r.state_dict().keys()) == list(m.state_dict().keys());"
         "assert all(a.shape == b.shape for a, b in zip(r.state_dict().values(), m.state_dict().values()));"
@@ -344,3 +348,15 @@ def test_lightning_checkpoint_round_trip(tmp_path):
     epoch, _ = load_lightning_checkpoint(m2, path)
     assert epoch == 4 and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
     assert set(model_state_dict(raw)) == set(sd)
+
+
+def test_synth_matches_baseline_counts():
+    """the bench workload IS BASELINE.md's: per-stride voxel counts of seed 0 equal SURVEY.md 8(d)'s probe numbers"""
+    from lidog_amd import synth
+    for cfg in ("kitti120k", "source8k"):
+        vox, _ = synth.scan_voxels(0, cfg)
+        assert synth.stride_counts(vox) == synth.BASELINE_COUNTS[cfg], cfg
+    vox, _ = synth.mix3d_voxels(0)
+    assert synth.stride_counts(vox) == synth.BASELINE_COUNTS["nusc35k+mix3d"]
+    pts, _ = synth.scan_points(0, **synth.CONFIGS["kitti120k"])
+    assert pts.shape[0] == 120000
