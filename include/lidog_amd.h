@@ -176,6 +176,12 @@ int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int
 /* out[c] = sum over the n rows of x[., c] for a narrow matrix (C <= 16; the classifier's bias gradient); ws: 512*C
  * doubles */
 int lidog_colsum(const float *x, int64_t n, int32_t C, float *out, double *ws, void *stream);
+int64_t lidog_colsum_ws(int32_t C); /* doubles of workspace lidog_colsum needs */
+/* evaluation-mode BatchNorm (running statistics, minkunet_bev.py:376-393 validation path): invstd = 1/sqrt(var+eps) */
+int lidog_bn_eval_invstd(const float *running_var, float eps, int32_t C, float *invstd, void *stream);
+/* ME.cat(a, b) on one coordinate map (minkunet_bev.py:337,348,359,370) and its backward (two contiguous gradients) */
+int lidog_cat2(const float *a, int32_t Ca, const float *b, int32_t Cb, int64_t n, float *out, void *stream);
+int lidog_split2(const float *g, int32_t Ca, int32_t Cb, int64_t n, float *ga, float *gb, void *stream);
 int lidog_relu_fwd(const float *x, int64_t n, float *y, void *stream);
 int lidog_relu_bwd(const float *dy, const float *y, int64_t n, float *dx, void *stream);
 int lidog_add(const float *a, const float *b, int64_t n, float *out, void *stream);
@@ -197,11 +203,12 @@ int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *winner, con
                        float *out /*[B,C,Ho,Wo]*/,
                        int32_t *argsrc /*[B,C,Ho,Wo] row*C+c of the arg-max cell or -1*/, uint64_t *rowbits,
                        void *stream);
-/* rowbits / Wo (rowbits may be NULL): the bitmasks lidog_bev_pool_fwd wrote -- argsrc is then read only where a bit
- * is set (it is NOT initialised elsewhere when the forward call was given bitmasks) */
-int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems, const int32_t *winner,
-                       const int32_t *pixel, int64_t n, int32_t C, float *gcell /*[n,C] zeroed scratch*/,
-                       float *gfeats /*[n,C]*/, const uint64_t *rowbits, int32_t Wo, void *stream);
+/* Backward of lidog_bev_pool_fwd as a gather over (voxel row, channel), no atomics (bit-reproducible): every row that
+ * targets a pixel receives the gradient of the pixel's winning row's cells (index_put's backward, minkunet_bev.py:217),
+ * a cell's gradient is the sum over the windows whose arg-max it was, in ascending window order. */
+int lidog_bev_pool_bwd(const float *gout /*[B,C,Ho,Wo]*/, const int32_t *argsrc, const int32_t *winner,
+                       const int32_t *pixel, int64_t n, int32_t C, int32_t B, int32_t H, int32_t W, int32_t pk,
+                       int32_t ps, int32_t pp, int32_t Ho, int32_t Wo, float *gfeats /*[n,C]*/, void *stream);
 
 /* ------------------------------------------------------------------ dense 2-D BEV head (MFMA)
  * Replaces nn.Conv2d(k3,s2,p1,bias=False) x2 and nn.Conv2d(k1) of Encoder2D

@@ -41,12 +41,16 @@ SIGNATURES = {
     "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p],
     "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
     "lidog_colsum": [_p, _i64, _i32, _p, _p, _p],
+    "lidog_colsum_ws": [_i32],
+    "lidog_bn_eval_invstd": [_p, _f, _i32, _p, _p],
+    "lidog_cat2": [_p, _i32, _p, _i32, _i64, _p, _p],
+    "lidog_split2": [_p, _i32, _i32, _i64, _p, _p, _p],
     "lidog_relu_fwd": [_p, _i64, _p, _p],
     "lidog_relu_bwd": [_p, _p, _i64, _p, _p],
     "lidog_add": [_p, _p, _i64, _p, _p],
     "lidog_bev_winner": [_p, _i64, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_bev_pool_fwd": [_p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p],
-    "lidog_bev_pool_bwd": [_p, _p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p],
+    "lidog_bev_pool_bwd": [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_conv2d_fwd": [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_conv2d_dgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_conv2d_wgrad": [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
@@ -72,7 +76,7 @@ SIGNATURES = {
     "lidog_allreduce_f64": [_p, _i64, _p, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
-             "lidog_dice_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}
+             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}
 
 _lib = None
 

@@ -230,72 +230,63 @@ extern "C" int lidog_bev_pool_fwd(const float *feats, int32_t C, const int32_t *
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_bev_pool_bwd_cells(const float *__restrict__ gout,
-                                                            const int32_t *__restrict__ argsrc, int64_t total,
-                                                            float *gcell) {
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    int32_t s = argsrc[e];
-    if (s >= 0) atomicAdd(&gcell[s], gout[e]);
-}
-
-// the same through the row bitmasks of lidog_bev_pool_fwd: only computed windows can have a source cell, so one
-// lane per 64-column word walks its set bits (0.34 -> ~0.05 ms on a LiDAR sweep: 95 % of the words are zero)
-__global__ __launch_bounds__(256) void k_bev_pool_bwd_cells_bits(const float *__restrict__ gout,
-                                                                 const int32_t *__restrict__ argsrc,
-                                                                 const unsigned long long *__restrict__ rowbits,
-                                                                 int64_t n_words, int words, int Wo, float *gcell) {
-    // a wave owns 64 consecutive words; every non-zero one is then handled by the whole wave, lane = column of
-    // the word (coalesced reads of the source map and of the gradient)
-    const int lane = threadIdx.x & 63;
-    const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) - lane;
-    const int64_t wi = w0 + lane;
-    const unsigned long long mine = wi < n_words ? rowbits[wi] : 0ull;
-    unsigned long long todo = __ballot(mine != 0ull);
-    while (todo) {
-        const int j = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const unsigned long long m = __shfl(mine, j);
-        const int64_t wj = w0 + j;
-        const int64_t row = wj / words;
-        const int x = (int)(wj - row * words) * 64 + lane;
-        if ((m >> lane) & 1ull) {
-            const int64_t e = row * Wo + x;
-            const int32_t s = argsrc[e];
-            if (s >= 0) atomicAdd(&gcell[s], gout[e]);
-        }
+// Backward of the fused scatter + view + max-pool, as a GATHER (no atomics: bit-reproducible).  One thread per
+// (voxel row i, channel c): the row's pixel belongs to the winner row w (index_put's backward is a gather: EVERY row that
+// targets a pixel receives that pixel's gradient); cell (w, c) sits at flat index f = q*C + c of the viewed image
+// -> (c', yy, xx); it can be the arg-max of the at most ceil(pk/ps)^2 windows that cover it, whose gradients are
+// added in ascending (yo, xo) order when argsrc says this cell was their maximum.  Every window covering a cell of an
+// occupied pixel was computed by the forward pass, so argsrc is defined wherever it is read here.
+__global__ __launch_bounds__(256) void k_bev_pool_bwd_gather(const float *__restrict__ gout,
+                                                             const int32_t *__restrict__ argsrc,
+                                                             const int32_t *__restrict__ winner,
+                                                             const int32_t *__restrict__ pixel, int64_t n, PoolGeom g,
+                                                             float *__restrict__ gfeats) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * g.C) return;
+    const int64_t i = idx / g.C;
+    const int c = (int)(idx - i * g.C);
+    const int pixi = pixel[i];
+    float acc = 0.f;
+    if (pixi >= 0) {
+        const unsigned HW = (unsigned)g.H * (unsigned)g.W;
+        const unsigned b = (unsigned)pixi / HW;
+        const unsigned q = (unsigned)pixi - b * HW;
+        const int32_t cell = winner[pixi] * g.C + c;
+        const unsigned f = q * (unsigned)g.C + (unsigned)c;
+        const unsigned cp = f / HW;
+        const unsigned r = f - cp * HW;
+        const int yy = (int)(r / (unsigned)g.W);
+        const int xx = (int)(r - (unsigned)yy * (unsigned)g.W);
+        const int t0 = yy + g.pp - g.pk + 1, t1 = xx + g.pp - g.pk + 1;
+        const int yo_lo = t0 > 0 ? (t0 + g.ps - 1) / g.ps : 0;
+        const int xo_lo = t1 > 0 ? (t1 + g.ps - 1) / g.ps : 0;
+        int yo_hi = (yy + g.pp) / g.ps, xo_hi = (xx + g.pp) / g.ps;
+        if (yo_hi > g.Ho - 1) yo_hi = g.Ho - 1;
+        if (xo_hi > g.Wo - 1) xo_hi = g.Wo - 1;
+        const size_t plane = ((size_t)b * g.C + cp) * ((size_t)g.Ho * g.Wo);
+        for (int yo = yo_lo; yo <= yo_hi; ++yo)
+            for (int xo = xo_lo; xo <= xo_hi; ++xo) {
+                const size_t e = plane + (size_t)yo * g.Wo + xo;
+                if (argsrc[e] == cell) acc += gout[e];
+            }
     }
+    gfeats[idx] = acc;
 }
 
-// index_put's backward is a gather: EVERY row that targets a pixel receives that pixel's gradient
-__global__ __launch_bounds__(256) void k_bev_pool_bwd_rows(const float *__restrict__ gcell,
-                                                           const int32_t *__restrict__ winner,
-                                                           const int32_t *__restrict__ pixel, int64_t n, int C,
-                                                           float *__restrict__ gfeats) {
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * C) return;
-    int64_t i = idx / C;
-    int c = (int)(idx % C);
-    int pix = pixel[i];
-    float g = 0.f;
-    if (pix >= 0) g = gcell[(int64_t)winner[pix] * C + c];
-    gfeats[idx] = g;
-}
-
-extern "C" int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, int64_t n_out_elems,
-                                  const int32_t *winner, const int32_t *pixel, int64_t n, int32_t C, float *gcell,
-                                  float *gfeats, const uint64_t *rowbits, int32_t Wo, void *stream) {
+extern "C" int lidog_bev_pool_bwd(const float *gout, const int32_t *argsrc, const int32_t *winner,
+                                  const int32_t *pixel, int64_t n, int32_t C, int32_t B, int32_t H, int32_t W,
+                                  int32_t pk, int32_t ps, int32_t pp, int32_t Ho, int32_t Wo, float *gfeats,
+                                  void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (n_out_elems && rowbits) {
-        LIDOG_REQUIRE(Wo > 0 && n_out_elems % Wo == 0, "bev_pool_bwd: Wo must divide the number of output elements");
-        const int words = (Wo + 63) / 64;
-        const int64_t n_words = n_out_elems / Wo * words;
-        k_bev_pool_bwd_cells_bits<<<(unsigned)cdiv64(n_words, 256), 256, 0, st>>>(
-            gout, argsrc, reinterpret_cast<const unsigned long long *>(rowbits), n_words, words, Wo, gcell);
-    } else if (n_out_elems)
-        k_bev_pool_bwd_cells<<<(unsigned)cdiv64(n_out_elems, 256), 256, 0, st>>>(gout, argsrc, n_out_elems, gcell);
-    if (n)
-        k_bev_pool_bwd_rows<<<(unsigned)cdiv64(n * C, 256), 256, 0, st>>>(gcell, winner, pixel, n, C, gfeats);
+    (void)B;
+    if (n == 0) return 0;
+    LIDOG_REQUIRE((int64_t)H * W * C < ((int64_t)1 << 31), "bev_pool_bwd: C*H*W must stay below 2^31");
+    LIDOG_REQUIRE(pk >= 1 && pk <= 8 && ps >= 1 && 2 * pp <= pk, "bev_pool_bwd: bad pooling geometry");
+    PoolGeom g;
+    g.C = C; g.H = H; g.W = W; g.pk = pk; g.ps = ps; g.pp = pp; g.Ho = Ho; g.Wo = Wo;
+    g.w_div_c = W / C; g.w_mod_c = W % C;
+    g.c_magic = (((uint64_t)1 << 40) + (uint64_t)C - 1) / (uint64_t)C;
+    k_bev_pool_bwd_gather<<<(unsigned)cdiv64(n * C, 256), 256, 0, st>>>(gout, argsrc, winner, pixel, n, g, gfeats);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

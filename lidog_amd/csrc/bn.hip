@@ -550,14 +550,81 @@ __global__ void k_colsum_finish(const double *__restrict__ partial, int nb, int 
     out[c] = (float)s;
 }
 
+// doubles of workspace lidog_colsum needs for C columns
+extern "C" int64_t lidog_colsum_ws(int32_t C) {
+    if (C <= 16) return (int64_t)COLSUM_BLOCKS * C;
+    return (int64_t)(2 * C + 2) + lidog_bn_reduce_ws(C, 1);
+}
+
 extern "C" int lidog_colsum(const float *x, int64_t n, int32_t C, float *out, double *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    LIDOG_REQUIRE(C >= 1 && C <= 16, "colsum: 1 <= C <= 16");
-    LIDOG_REQUIRE(ws != nullptr, "colsum: needs a workspace of 512 * C doubles");
+    LIDOG_REQUIRE(C >= 1, "colsum: C >= 1");
+    LIDOG_REQUIRE(ws != nullptr, "colsum: needs a workspace of lidog_colsum_ws(C) doubles");
     if (n == 0) return hipMemsetAsync(out, 0, sizeof(float) * C, st) == hipSuccess ? 0 : 1;
+    if (C > 16) {
+        // wide case (a bias gradient of a wide convolution; `final` of the LiDOG path has 7 columns): the BatchNorm
+        // statistics reduction, whose last kernel stores the float copy of the first sum
+        BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, out};
+        return launch_colreduce<0>(x, nullptr, nullptr, n, C, 1, nullptr, nullptr, ws, ws + 2 * C + 2, 0.0, fin, st);
+    }
     int nb = (int)(cdiv64(n, 1024) < COLSUM_BLOCKS ? cdiv64(n, 1024) : COLSUM_BLOCKS);
     k_colsum_narrow<<<nb, 256, 0, st>>>(x, n, C, ws);
     k_colsum_finish<<<1, 64, 0, st>>>(ws, nb, C, out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// invstd of an evaluation-mode BatchNorm (running statistics): 1 / sqrt(running_var + eps)
+__global__ void k_bn_eval_invstd(const float *__restrict__ var, float eps, int C, float *__restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = (float)(1.0 / sqrt((double)var[c] + (double)eps));
+}
+
+extern "C" int lidog_bn_eval_invstd(const float *running_var, float eps, int32_t C, float *invstd, void *stream) {
+    if (C == 0) return 0;
+    k_bn_eval_invstd<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(running_var, eps, C, invstd);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ME.cat of two feature matrices on one coordinate map: out[i] = (a[i], b[i]); the backward pass splits the gradient
+// back into two contiguous matrices (torch.cat's backward hands out strided views, which every consumer then copies)
+__global__ __launch_bounds__(256) void k_cat2(const float4 *__restrict__ a, int Ca4, const float4 *__restrict__ b,
+                                              int Cb4, int64_t n, float4 *__restrict__ out) {
+    const int C4 = Ca4 + Cb4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * C4) return;
+    const int64_t i = idx / C4;
+    const int c = (int)(idx - i * C4);
+    out[idx] = c < Ca4 ? a[i * Ca4 + c] : b[i * Cb4 + (c - Ca4)];
+}
+
+__global__ __launch_bounds__(256) void k_split2(const float4 *__restrict__ g, int Ca4, int Cb4, int64_t n,
+                                                float4 *__restrict__ ga, float4 *__restrict__ gb) {
+    const int C4 = Ca4 + Cb4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * C4) return;
+    const int64_t i = idx / C4;
+    const int c = (int)(idx - i * C4);
+    const float4 v = g[idx];
+    if (c < Ca4) ga[i * Ca4 + c] = v;
+    else gb[i * Cb4 + (c - Ca4)] = v;
+}
+
+extern "C" int lidog_cat2(const float *a, int32_t Ca, const float *b, int32_t Cb, int64_t n, float *out, void *stream) {
+    LIDOG_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "cat2: channel counts must be positive multiples of 4");
+    if (n == 0) return 0;
+    k_cat2<<<(unsigned)cdiv64(n * ((Ca + Cb) / 4), 256), 256, 0, (hipStream_t)stream>>>(
+        (const float4 *)a, Ca / 4, (const float4 *)b, Cb / 4, n, (float4 *)out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lidog_split2(const float *g, int32_t Ca, int32_t Cb, int64_t n, float *ga, float *gb, void *stream) {
+    LIDOG_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "split2: channel counts must be positive multiples of 4");
+    if (n == 0) return 0;
+    k_split2<<<(unsigned)cdiv64(n * ((Ca + Cb) / 4), 256), 256, 0, (hipStream_t)stream>>>(
+        (const float4 *)g, Ca / 4, Cb / 4, n, (float4 *)ga, (float4 *)gb);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
         if (tid < rows) {
             src = gather ? gather[row0 + tid] : (row0 + tid);
             dst = scatter ? scatter[row0 + tid] : (row0 + tid);
+#ifdef MG_EXP_NOGATHER   // experiment: consecutive (coalesced, cache-resident) source rows instead of the gather
+            src = (row0 + tid) & 0xFFFF;
+#endif
         }
         s_src[tid] = src;
         s_dst[tid] = dst;
@@ -148,6 +151,16 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    // bias of this lane's NT columns (+0 when there is none: x + 0 == x bit for bit, also for -0 results? no:
+    // -0 + +0 = +0, so the no-bias case adds -0.0f, the identity of IEEE addition)
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = -0.0f;
+    if (bias) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = bias[col0 + li * NT + t];
+    }
+
     load_chunk(0);
     for (int kb = 0; kb < Cin; kb += MG_BK) {
         __syncthreads();
@@ -155,7 +168,10 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
         __syncthreads();
         // unconditional prefetch (the last iteration re-reads its own chunk): a branch around the staging
         // registers sends them through scratch memory
+#ifndef MG_EXP_NOLOAD    // experiment: no global loads inside the loop
         load_chunk(kb + MG_BK < Cin ? kb + MG_BK : kb);
+#endif
+#ifndef MG_EXP_NOMFMA    // experiment: data movement only
         const float *arow = &As[(wave * 32 + li) * MG_SA + kh];
         // MFMA column tile t of this wave = columns {li * NT + t}: the NT B operands of one k step are adjacent
         // in the row-major LDS image (one wide LDS read), and the NT results of a lane are adjacent in T (one
@@ -193,23 +209,34 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict
                 a1 = an1;
             }
         }
+#endif
     }
 
-    float bv[NT];
+    // Epilogue.  Nothing may be pending in vmcnt here except the stores themselves: with a load outstanding (the bias
+    // used to be fetched at this point) hipcc puts `s_waitcnt vmcnt(0)` in front of EVERY predicated store of the
+    // loop below, and each store then waits for the previous one to be acknowledged by memory (the 16 stores of a
+    // wave serialised: 11 % of the whole kernel, 17 % on the 96-column layers).  The bias is therefore loaded before
+    // the main loop; rows past the end of the tile are skipped by the exec mask, which needs no wait.
+    // (the bias is also ADDED here, in straight-line code: a first use inside the predicated blocks below would bring
+    // the per-store wait back; for the same reason the staging loads of the loop's last, redundant prefetch are
+    // drained once, here: vmcnt(0), expcnt / lgkmcnt untouched)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[col0 + li * NT + t] : 0.f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] += bv[t];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         int dst = s_dst[r];
+#ifdef MG_EXP_NOSTORE    // experiment: no product-row stores (kept live by a never-true condition)
+        if (acc[0][e] != 1.2345e30f) dst = -1;
+#endif
         if (dst >= 0) {
             float *out = T + (size_t)dst * Cout + col0 + li * NT;
             float v[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                v[t] = acc[t][e];
-                if (bias) v[t] += bv[t];
-            }
+            for (int t = 0; t < NT; ++t) v[t] = acc[t][e];
             frag_store<NT>(out, v);
         }
     }

@@ -2,14 +2,13 @@
 
   SoftDICELoss  utils/losses/losses.py:100-109,129-187  (powerize, present-class mask, eps = 0.05)
   DICELoss      utils/losses/losses.py:56-97            (hard one-hot, no mask)
-Same formulas as the reference; the `.cpu()` round trips (losses.py:72-73,148-149) are gone, and rows carrying
-the ignore label are masked (weight 0) instead of being compacted away with boolean indexing: the compaction
-needs the number of valid rows on the host, i.e. a device synchronisation in the middle of every step.  Masked
-rows add exact zeros to every sum, so the loss is the same up to the rounding of a different summation tree.
+Same formulas as the reference, as HIP kernels (csrc/losses.hip; there is no torch formula behind them: CPU tensors and
+unsupported class counts raise); the `.cpu()` round trips (losses.py:72-73,148-149) are gone, and rows carrying the
+ignore label are skipped in place instead of being compacted away with boolean indexing: the compaction needs the
+number of valid rows on the host, i.e. a device synchronisation in the middle of every step.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib
 from ._lib import call, ptr
@@ -47,25 +46,12 @@ class _DiceFn(torch.autograd.Function):
         return g, None, None, None, None, None, None, None
 
 
-def _fused(output):
-    return output.is_cuda and output.dim() == 2 and output.shape[1] in _FUSED_CLASSES and \
-        output.dtype == torch.float32
-
-
-def _dice(prob, target_w, present, powerize):
-    inter = (prob * target_w).sum(dim=0)
-    union = ((prob.pow(2) if powerize else prob).sum(dim=0) + target_w.sum(dim=0)) + 1e-12
-    iou = (present * 2 * inter / union).sum(dim=0) / (present.sum(dim=0) + 1e-12)
-    return 1 - iou.mean()
-
-
-def _masked_onehot(target, C, ignore_label):
-    """one-hot rows of `target` with all-zero rows where target == ignore_label; (onehot, row weight or None)"""
-    if ignore_label is None:
-        return F.one_hot(target, num_classes=C), None
-    valid = target != ignore_label
-    onehot = F.one_hot(torch.where(valid, target, torch.zeros_like(target)), num_classes=C) * valid.unsqueeze(1)
-    return onehot, valid.unsqueeze(1).to(torch.float32)
+def _check(output):
+    """the DICE losses exist as HIP kernels only (csrc/losses.hip): no torch formula behind them"""
+    _lib.require_gpu(output, "logits")
+    if output.dim() != 2 or output.shape[1] not in _FUSED_CLASSES or output.dtype != torch.float32:
+        raise NotImplementedError(f"lidog_amd DICE losses take float32 logits [n, C] with C in {_FUSED_CLASSES}, "
+                                  f"got {tuple(output.shape)} {output.dtype}")
 
 
 class SoftDICELoss(nn.Module):
@@ -77,20 +63,9 @@ class SoftDICELoss(nn.Module):
             ignore_label, powerize, use_tmask, neg_range, eps
 
     def forward(self, output, target):
-        if _fused(output):
-            return _DiceFn.apply(output, target, self.ignore_label, self.eps, True, self.powerize, self.use_tmask,
-                                 -1.0 if self.neg_range else 0.0)
-        # host-side formula (CPU tensors in unit tests, unusual class counts)
-        C = output.shape[1]
-        onehot, w = _masked_onehot(target, C, self.ignore_label)
-        soft = torch.where(onehot == 1, 1 - self.eps, self.eps / (C - 1)).to(torch.float32)
-        prob = F.softmax(output, dim=-1)
-        if w is not None:
-            soft, prob = soft * w, prob * w
-        present = (onehot.sum(dim=0) > 0).int() if self.use_tmask else torch.ones(C, dtype=torch.int32,
-                                                                                  device=output.device)
-        loss = _dice(prob, soft, present, self.powerize)
-        return loss - 1 if self.neg_range else loss
+        _check(output)
+        return _DiceFn.apply(output, target, self.ignore_label, self.eps, True, self.powerize, self.use_tmask,
+                             -1.0 if self.neg_range else 0.0)
 
 
 class DICELoss(nn.Module):
@@ -99,13 +74,5 @@ class DICELoss(nn.Module):
         self.ignore_label, self.powerize, self.use_tmask = ignore_label, powerize, use_tmask
 
     def forward(self, output, target):
-        if _fused(output):
-            return _DiceFn.apply(output, target, self.ignore_label, 0.0, False, self.powerize, self.use_tmask, 0.0)
-        C = output.shape[1]
-        onehot, w = _masked_onehot(target, C, self.ignore_label)
-        prob = F.softmax(output, dim=-1)
-        if w is not None:
-            prob = prob * w
-        present = (onehot.sum(dim=0) > 0).int() if self.use_tmask else torch.ones(C, dtype=torch.int32,
-                                                                                  device=output.device)
-        return _dice(prob, onehot, present, self.powerize)
+        _check(output)
+        return _DiceFn.apply(output, target, self.ignore_label, 0.0, False, self.powerize, self.use_tmask, 0.0)

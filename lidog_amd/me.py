@@ -477,9 +477,13 @@ class SparseTensor:
 
 
 def cat(*tensors):
+    """ME.cat: feature matrices of tensors on ONE coordinate map side by side (minkunet_bev.py:337,348,359,370)"""
     for t in tensors[1:]:
         tensors[0]._same_map(t)
-    return tensors[0]._like(torch.cat([t.F for t in tensors], dim=1))
+    out = tensors[0].F
+    for t in tensors[1:]:
+        out = _Cat2Fn.apply(out, t.F)
+    return tensors[0]._like(out)
 
 
 # ------------------------------------------------------------------ autograd functions over the C ABI
@@ -494,6 +498,28 @@ class _AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+class _Cat2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        n, Ca, Cb = a.shape[0], a.shape[1], b.shape[1]
+        if b.shape[0] != n:
+            raise ValueError("cat: feature matrices of different lengths")
+        out = torch.empty((n, Ca + Cb), dtype=torch.float32, device=a.device)
+        call("lidog_cat2", ptr(a), Ca, ptr(b), Cb, n, ptr(out))
+        ctx.shape = (n, Ca, Cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, Ca, Cb = ctx.shape
+        g = g.contiguous()
+        ga = torch.empty((n, Ca), dtype=torch.float32, device=g.device)
+        gb = torch.empty((n, Cb), dtype=torch.float32, device=g.device)
+        call("lidog_split2", ptr(g), Ca, Cb, n, ptr(ga), ptr(gb))
+        return ga, gb
 
 
 class _ReLUFn(torch.autograd.Function):
@@ -729,13 +755,10 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and gW is None:
             gW = queue_wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            if Cout <= 16:
-                gb = _grad_out(ctx.b_param, (1, Cout))
-                gb = gb if gb is not None else torch.empty((1, Cout), dtype=torch.float32, device=x.device)
-                ws = torch.empty(512 * Cout, dtype=torch.float64, device=x.device)
-                call("lidog_colsum", ptr(gout), gout.shape[0], Cout, ptr(gb), ptr(ws))
-            else:
-                gb = gout.sum(dim=0, keepdim=True)
+            gb = _grad_out(ctx.b_param, (1, Cout))
+            gb = gb if gb is not None else torch.empty((1, Cout), dtype=torch.float32, device=x.device)
+            ws = torch.empty(_lib.load().lidog_colsum_ws(Cout), dtype=torch.float64, device=x.device)
+            call("lidog_colsum", ptr(gout), gout.shape[0], Cout, ptr(gb), ptr(ws))
         if gskip is not None:   # paths without a reduction pass (1x1, k2 s2) or no data gradient asked for
             gx = gskip if gx is None else gx + gskip
         return gx, gW, gb, None, None, None, None, None, None
@@ -805,7 +828,8 @@ class _BatchNormFn(torch.autograd.Function):
                      ptr(running_mean), ptr(running_var))
         else:
             mean = running_mean
-            invstd = torch.rsqrt(running_var + eps)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            call("lidog_bn_eval_invstd", ptr(running_var), float(eps), C, ptr(invstd))
         y = torch.empty_like(x)
         res = residual.contiguous() if residual is not None else None
         call("lidog_bn_apply", ptr(x), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(res),

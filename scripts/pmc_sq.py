@@ -4,7 +4,7 @@ dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
 flt = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--filter=")]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for d in dirs:
-    for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][-48:]
             if flt and not any(x in r["Kernel_Name"] for x in flt):

@@ -136,15 +136,22 @@ def test_first_bev_convolution_over_the_support_of_a_real_scan():
     call("lidog_conv2d_wgrad", ptr(x), ptr(gy), B, Cin, H, W, Cout, 3, 2, 1, ptr(gw_d), None, ptr(wsw), wsw.numel())
     call("lidog_conv2d_wgrad_sparse", ptr(x), ptr(gy), ptr(act), B, Cin, H, W, Cout, ptr(gw_s), ptr(wsw), wsw.numel())
     assert float((gw_s - gw_d).abs().max()) <= 1e-5 * float(gw_d.abs().max())
-    # pooling backward: bitmask walk (what the model runs) == dense walk over the whole source map
+    # pooling backward (gather form, no atomics): equal to an index_add over the source map, and run-to-run identical
     gout = torch.randn_like(img)
     winner, pixel, argsrc, _ = img.grad_fn.saved_tensors
     img.backward(gout)
-    gcell, gfe = torch.zeros(n, 96, device="cuda"), torch.empty(n, 96, device="cuda")
     src = torch.where(need, argsrc, torch.full_like(argsrc, -1))         # argsrc is only defined on the support
-    call("lidog_bev_pool_bwd", ptr(gout), ptr(src), gout.numel(), ptr(winner), ptr(pixel), n, 96, ptr(gcell), ptr(gfe),
-         None, W)
-    torch.testing.assert_close(feats.grad, gfe, rtol=1e-5, atol=1e-6)    # float atomics: equal up to summation order
+    ok = src >= 0
+    gcell = torch.zeros(n * 96, device="cuda", dtype=torch.float64)
+    gcell.index_add_(0, src[ok].long(), gout[ok].double())
+    pix = pixel.long()
+    ref = torch.where((pix >= 0).unsqueeze(1), gcell.view(n, 96)[winner.view(-1)[pix.clamp(min=0)].long().clamp(min=0)],
+                      torch.zeros((), device="cuda", dtype=torch.float64))
+    torch.testing.assert_close(feats.grad.double(), ref, rtol=1e-6, atol=1e-7)
+    gfe = torch.empty(n, 96, device="cuda")
+    Bp, _, Hp, Wp = winner.shape[0], None, winner.shape[1], winner.shape[2]
+    call("lidog_bev_pool_bwd", ptr(gout), ptr(argsrc), ptr(winner), ptr(pixel), n, 96, Bp, Hp, Wp, 5, 3, 1, H, W, ptr(gfe))
+    assert torch.equal(gfe, feats.grad)                                  # bit-identical from run to run
 
 
 @pytest.mark.parametrize("name", ["c1_source8k", "c4_mix3d"])

@@ -89,6 +89,7 @@ CONV_CASES = [
     (96, 7, 1, 1, False, True),
     (192, 128, 1, 1, False, False),
     (20, 12, 3, 1, False, True),   # generic fallback kernels
+    (32, 64, 3, 1, False, True),   # bias gradient wider than 16 columns (BatchNorm statistics reduction)
 ]
 
 
@@ -185,7 +186,14 @@ def test_relu_add_cat():
     a = ME.SparseTensor(coordinates=coords.cuda(), features=x.cuda().requires_grad_(True))
     b = ME.SparseTensor(x.cuda() * 2, coordinate_manager=a.coordinate_manager, coordinate_map_key=1)
     c = ME.cat(a, b)
-    assert c.F.shape[1] == 48
+    assert c.F.shape[1] == 48 and torch.equal(c.F.cpu(), torch.cat([x, 2 * x], dim=1))
+    # backward of cat: two contiguous gradients (HIP split kernel), equal to torch's
+    xa, xb = x.cuda().requires_grad_(True), (3 * x).cuda().requires_grad_(True)
+    ca = ME.cat(ME.SparseTensor(xa, coordinate_manager=a.coordinate_manager, coordinate_map_key=1),
+                ME.SparseTensor(xb, coordinate_manager=a.coordinate_manager, coordinate_map_key=1))
+    w = torch.randn(coords.shape[0], 48, device="cuda")
+    (ca.F * w).sum().backward()
+    assert torch.equal(xa.grad, w[:, :24]) and torch.equal(xb.grad, w[:, 24:])
     r = ME.MinkowskiReLU(inplace=True)(a)
     assert torch.equal(r.F.cpu(), torch.relu(x))
     s = a + b
