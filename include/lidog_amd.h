@@ -142,6 +142,10 @@ int lidog_get_sparse_core(void);
 
 /* Wt[k][co][ci] = W[k][ci][co] */
 int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, int32_t Cout, float *Wt, void *stream);
+/* all kernels of a model at once (after the optimiser step): desc int64 [n_mats][6] = (src offset, dst offset, K, Cin,
+ * Cout, first 32x32 tile), offsets in floats into src / dst */
+int lidog_transpose_batched(const float *src, float *dst, const int64_t *desc, int32_t n_mats, int64_t total_tiles,
+                            void *stream);
 
 /* ------------------------------------------------------------------ BatchNorm / ReLU on COO features
  * Replaces ME.MinkowskiBatchNorm (nn.BatchNorm1d over all rows, minkunet_bev.py:60,406-408) and

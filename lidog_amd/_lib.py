@@ -34,6 +34,7 @@ SIGNATURES = {
     "lidog_set_sparse_core": [_i32],
     "lidog_get_sparse_core": [],
     "lidog_transpose_kernel": [_p, _i32, _i32, _i32, _p, _p],
+    "lidog_transpose_batched": [_p, _p, _p, _i32, _i64, _p],
     "lidog_bn_reduce_ws": [_i32, _i64],
     "lidog_bn_stats": [_p, _i64, _i32, _i64, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_bn_finalize": [_p, _d, _i32, _f, _f, _p, _p, _p, _p, _p],

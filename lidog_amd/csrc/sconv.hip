@@ -921,3 +921,48 @@ extern "C" int lidog_transpose_kernel(const float *W, int32_t K, int32_t Cin, in
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
+
+// Every [K][Cin][Cout] kernel of a model transposed to [K][Cout][Cin] in ONE launch (the data gradients of a backward
+// pass read the transposed weights; one launch after the optimiser step replaces one small kernel per convolution on
+// the backward pass's dependent chain).  desc[m] = (src offset, dst offset, K, Cin, Cout, first tile), offsets in
+// floats into `src` / `dst`; tiles are 32 x 32, enumerated per matrix as (k, ci tile, co tile).
+__global__ __launch_bounds__(256) void k_transpose_batched(const float *__restrict__ src, float *__restrict__ dst,
+                                                           const int64_t *__restrict__ desc, int n_mats) {
+    __shared__ float tile[32][33];
+    __shared__ int64_t s_d[6];
+    const int64_t t = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_mats - 1;   // last matrix whose first tile is <= t
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (desc[(size_t)mid * 6 + 5] <= t) lo = mid;
+            else hi = mid - 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s_d[j] = desc[(size_t)lo * 6 + j];
+    }
+    __syncthreads();
+    const int Cin = (int)s_d[3], Cout = (int)s_d[4];
+    const int tco = (Cout + 31) / 32, tci = (Cin + 31) / 32;
+    const int64_t local = t - s_d[5];
+    const int k = (int)(local / (tci * tco));
+    const int r = (int)(local - (int64_t)k * tci * tco);
+    const int ci0 = (r / tco) * 32, co0 = (r % tco) * 32;
+    const float *W = src + s_d[0] + (size_t)k * Cin * Cout;
+    float *Wt = dst + s_d[1] + (size_t)k * Cin * Cout;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int rr = ty; rr < 32; rr += 8)
+        if (ci0 + rr < Cin && co0 + tx < Cout) tile[rr][tx] = W[(size_t)(ci0 + rr) * Cout + co0 + tx];
+    __syncthreads();
+    for (int rr = ty; rr < 32; rr += 8)
+        if (co0 + rr < Cout && ci0 + tx < Cin) Wt[(size_t)(co0 + rr) * Cin + ci0 + tx] = tile[tx][rr];
+}
+
+extern "C" int lidog_transpose_batched(const float *src, float *dst, const int64_t *desc, int32_t n_mats,
+                                       int64_t total_tiles, void *stream) {
+    if (n_mats == 0 || total_tiles == 0) return 0;
+    LIDOG_REQUIRE(total_tiles < ((int64_t)1 << 31), "transpose_batched: too many tiles");
+    k_transpose_batched<<<(unsigned)total_tiles, 256, 0, (hipStream_t)stream>>>(src, dst, desc, n_mats);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}

@@ -169,8 +169,12 @@ __global__ __launch_bounds__(256) void k_sconv_os(const float *__restrict__ A, c
             for (int s = 0; s < 16 * NCH; ++s) bc[s] = bn[s];
             __syncthreads();
             // in flight during this tile's MFMAs: rows and B fragments of tile t + 1, indices of tile t + 3
+#ifndef OS_EXP_NOA
             if (t + 1 < n_tiles) load_rows((t + 1) % 3);
+#endif
+#ifndef OS_EXP_NOB
             load_b(t + 1, bn);
+#endif
             idx_ahead = load_idx(t + 3);
 
             if (wave_on) {
@@ -186,18 +190,28 @@ __global__ __launch_bounds__(256) void k_sconv_os(const float *__restrict__ A, c
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#ifndef OS_EXP_NOMFMA
 #pragma unroll
                 for (int s = 0; s < 16 * NCH; ++s)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bc[s], acc, 0, 0, 0);
+#else
+#pragma unroll
+                for (int s = 0; s < 16 * NCH; ++s) acc[s & 15] += av[s] * bc[s];
+#endif
                 float *blk = acc_blk + 32 * wave + li;
                 // the wave owns these columns and the rows of a tile are distinct: plain read-add-write, all reads
                 // first (an LDS float atomic costs ~150 cycles per wave instruction here); padding rows go to the
                 // spare row OS_BR
                 float cur[16];
+#ifndef OS_EXP_NORMW
 #pragma unroll
                 for (int e = 0; e < 16; ++e) cur[e] = blk[(dst[e] < 0 ? OS_BR : dst[e]) * CTP];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) blk[(dst[e] < 0 ? OS_BR : dst[e]) * CTP] = cur[e] + acc[e];
+#else
+                if (acc[0] == 1.2345e30f) blk[0] = acc[1];
+                (void)cur;
+#endif
             }
         }
     }

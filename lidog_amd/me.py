@@ -736,8 +736,12 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not behind:
             gW = queue_wgrad()
         if ctx.needs_input_grad[0]:
-            Wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
-            call("lidog_transpose_kernel", ptr(W3), K, Cin, Cout, ptr(Wt))
+            wp = ctx.w_param
+            if getattr(wp, "_wt_version", -2) == wp._version:
+                Wt = wp._wt_view                     # refreshed after the optimiser step (optim.TransposedKernels)
+            else:
+                Wt = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
+                call("lidog_transpose_kernel", ptr(W3), K, Cin, Cout, ptr(Wt))
             gx = torch.empty((n_in, Cin), dtype=torch.float32, device=x.device)
             if identity:
                 _gemm(gout, None, Wt, None, m, Cout, Cin, gx, None)
@@ -928,6 +932,7 @@ class _ConvBase(nn.Module):
         shape = (self.kernel_volume, in_channels, out_channels) if self.kernel_volume > 1 else \
             (in_channels, out_channels)
         self.kernel = nn.Parameter(torch.empty(shape))
+        self.kernel._lidog_sparse_kernel = True   # lidog_amd.optim.TransposedKernels keeps a [K, Cout, Cin] copy
         self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
         self.reset_parameters()
 

@@ -166,6 +166,44 @@ class GradientBuckets:
         self.pending = list(self.pending0)
 
 
+class TransposedKernels:
+    """[K, Cout, Cin] copies of every sparse-convolution kernel [K, Cin, Cout] of the model (what the data gradients of
+    the backward pass multiply by), refreshed by ONE launch after each optimiser step instead of one small transpose
+    kernel per convolution inside the backward pass's dependent chain (63 launches per step).  A copy is used only
+    while the parameter's version counter still has the value it had at the refresh: weights changed by anything
+    else (load_state_dict, an in-place edit) fall back to the per-layer transpose (me._SparseConvFn.backward)."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.items = []
+        desc, off, tiles = [], 0, 0
+        for p, src in zip(flat.params, flat.offsets):
+            if not getattr(p, "_lidog_sparse_kernel", False):
+                continue
+            shape = p.shape if p.dim() == 3 else (1,) + tuple(p.shape)
+            K, Cin, Cout = shape
+            desc.append((src, off, K, Cin, Cout, tiles))
+            self.items.append((p, off, (K, Cout, Cin)))
+            off += p.numel()
+            tiles += K * (-(-Cin // 32)) * (-(-Cout // 32))
+        self.total_tiles = tiles
+        dev = flat.flat.device
+        self.buf = torch.empty(off, dtype=torch.float32, device=dev)
+        self.desc = torch.tensor(desc, dtype=torch.int64, device=dev).view(-1, 6) if desc else None
+        for p, o, shape in self.items:
+            p._wt_view = self.buf[o:o + p.numel()].view(shape)
+            p._wt_version = -1
+        self.refresh()
+
+    def refresh(self):
+        if not self.items or not self.buf.is_cuda:
+            return
+        call("lidog_transpose_batched", ptr(self.flat.flat), ptr(self.buf), ptr(self.desc), len(self.items),
+             self.total_tiles)
+        for p, _, _ in self.items:
+            p._wt_version = p._version
+
+
 class _FlatOptimizer:
     """Common part of the fused optimisers: flat buffers, gradient buckets, and torch's rule that a parameter
     WITHOUT a gradient is skipped entirely (no weight decay, no moment decay, no step count) -- e.g. `final.*`
@@ -180,6 +218,7 @@ class _FlatOptimizer:
         if self.buckets.world > 1:
             self.flat.broadcast(group)     # DDP's start-up broadcast of rank 0's parameters
         self.strays = 0
+        self.transposed = TransposedKernels(self.flat)
 
     @property
     def steps(self):
@@ -225,6 +264,7 @@ class _FlatOptimizer:
             self.param_steps = list(sd["param_steps"])
         else:   # round-1 checkpoints stored one global step count
             self.param_steps = [int(sd["steps"])] * len(self.flat.params)
+        self.transposed.refresh()   # the model's weights were (re)loaded before this call
 
 
 class FlatAdam(_FlatOptimizer):
@@ -246,6 +286,7 @@ class FlatAdam(_FlatOptimizer):
             call("lidog_adam_step", ptr(f.flat[lo:hi]), ptr(f.grad[lo:hi]), ptr(self.exp_avg[lo:hi]),
                  ptr(self.exp_avg_sq[lo:hi]), hi - lo, float(self.lr), float(self.betas[0]), float(self.betas[1]),
                  float(self.eps), float(self.weight_decay), st, float(scale))
+        self.transposed.refresh()
 
 
 class FlatSGD(_FlatOptimizer):
@@ -268,6 +309,7 @@ class FlatSGD(_FlatOptimizer):
             call("lidog_sgd_step", ptr(f.flat[lo:hi]), ptr(f.grad[lo:hi]), ptr(self.momentum_buffer[lo:hi]), hi - lo,
                  float(self.lr), float(self.momentum), float(self.weight_decay), 1 if self.nesterov else 0,
                  float(scale))
+        self.transposed.refresh()
 
 
 def make_optimizer(name, model, lr, weight_decay=1e-4, momentum=0.98, group=None):

@@ -186,9 +186,23 @@ def g5_full_model():
         sem0, none0 = model(ME.SparseTensor(coordinates=C, features=feats), is_train=False)
     assert none0 is None
     out["eval_logits_initial"] = sem0.F.numpy().copy()
+    sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
+    # Full backward chain with BatchNorm in evaluation mode (running statistics), BEV head included: without batch
+    # statistics nothing amplifies summation-order noise, so these gradient vectors can be compared tightly (the
+    # training-mode gradients below move by 1 - cos = 2e-3..4e-3 when the SAME oracle merely runs on 8 threads)
+    sem_e, bev_e = model(ME.SparseTensor(coordinates=C, features=feats), is_train=True)
+    loss_e = 0.5 * sem_c(sem_e.F, labels).cpu() + 0.5 * bev_c(bev_e["block8"].view(-1, 7).cpu(), bev_labels.view(-1).cpu())
+    model.zero_grad()
+    loss_e.backward()
+    out["eval_loss"] = loss_e.detach().numpy()
+    for n in G5_GRAD_VECTORS:
+        gvec = dict(model.named_parameters())[n].grad.numpy()
+        scale = float(np.abs(gvec).max())
+        out[f"grad16_eval/{n}"] = (gvec / scale).astype(np.float16)
+        out[f"grad16scale_eval/{n}"] = np.float32(scale)
+    model.zero_grad()
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
     losses = []
     for step in range(3):
         st = ME.SparseTensor(coordinates=C, features=feats)

@@ -147,7 +147,7 @@ def test_first_bev_convolution_over_the_support_of_a_real_scan():
     pix = pixel.long()
     ref = torch.where((pix >= 0).unsqueeze(1), gcell.view(n, 96)[winner.view(-1)[pix.clamp(min=0)].long().clamp(min=0)],
                       torch.zeros((), device="cuda", dtype=torch.float64))
-    torch.testing.assert_close(feats.grad.double(), ref, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(feats.grad.double(), ref, rtol=1e-5, atol=1e-6)   # fp32 sums of <= 4 window gradients
     gfe = torch.empty(n, 96, device="cuda")
     Bp, _, Hp, Wp = winner.shape[0], None, winner.shape[1], winner.shape[2]
     call("lidog_bev_pool_bwd", ptr(gout), ptr(argsrc), ptr(winner), ptr(pixel), n, 96, Bp, Hp, Wp, 5, 3, 1, H, W, ptr(gfe))

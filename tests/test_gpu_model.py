@@ -7,6 +7,27 @@ import torch
 from helpers import GOLDEN, seeded_state_dict, sha_triples
 
 pytestmark = pytest.mark.gpu
+# Bars on 1 - cosine between a parameter's gradient vector here and in the golden run (float16-stored, which alone
+# costs 2e-8).  Evaluation-mode BatchNorm (running statistics): nothing amplifies summation-order noise, the whole
+# backward chain (data / weight gradients of all 63 convolutions, residual adds, cat / split, BEV pooling, the 2-D
+# head) must agree tightly.  Training-mode BatchNorm on this 5.8 k-voxel batch amplifies rounding noise: the CPU
+# oracle ITSELF, run on 8 threads instead of 1 (same code, another reduction order), moves its logits by 6.5e-5 and
+# these gradients by 1 - cos = 1.9e-3 .. 4.1e-3 against the golden run (round-2 experiment) -- the
+# figures the HIP path shows as well.
+COS_BAR_EVAL = 1 - 1e-6
+COS_BAR_TRAIN = 1 - 1e-2
+
+
+def _grad_report(g5, named, prefix):
+    names = [k[len(prefix) + 1:] for k in g5.files if k.startswith(prefix + "/")]
+    assert len(names) >= 10
+    rep = {}
+    for n in names:
+        ref = torch.from_numpy(g5[f"{prefix}/{n}"].astype(np.float32)).flatten().double() * \
+            float(g5[f"{prefix.replace('grad16', 'grad16scale')}/{n}"])
+        got = named[n].grad.detach().cpu().flatten().double()
+        rep[n] = (1 - float(torch.dot(got, ref) / (got.norm() * ref.norm())), float(got.norm() / ref.norm()))
+    return rep
 
 
 def _sha_coords(t):
@@ -51,9 +72,19 @@ def test_minkunet34bev_matches_reference_golden():
     iou_g = per_class_iou(preds, labels, 7, -1).cpu()
     iou_r = per_class_iou(ref_preds, labels.cpu(), 7, -1)
     assert (iou_g - iou_r).abs().max().item() <= 1e-3
+    # the whole backward chain, BatchNorm in evaluation mode (no batch statistics): tight bar
+    sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
+    sem_e, bev_e = model(ME.SparseTensor(coordinates=C, features=feats), is_train=True)
+    loss_e = 0.5 * sem_c(sem_e.F, labels) + 0.5 * bev_c(bev_e["block8"].view(-1, 7), bev_labels.view(-1))
+    assert abs(float(loss_e.detach()) - float(g5["eval_loss"])) <= 1e-5
+    model.zero_grad()
+    loss_e.backward()
+    rep = _grad_report(g5, dict(model.named_parameters()), "grad16_eval")
+    print("eval-mode 1 - cosine / norm ratio:", {n: (f"{a:.1e}", round(b, 6)) for n, (a, b) in rep.items()})
+    assert max(a for a, _ in rep.values()) <= 1 - COS_BAR_EVAL and max(abs(b - 1) for _, b in rep.values()) <= 1e-3, rep
+    model.zero_grad()
     model.train()
     opt = FlatAdam(model, lr=1e-3, weight_decay=1e-4)
-    sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
     losses = []
     for step in range(3):
         st = ME.SparseTensor(coordinates=C, features=feats)
@@ -95,19 +126,11 @@ def test_minkunet34bev_matches_reference_golden():
                 got = dict(model.named_parameters())[n].grad.cpu()
                 ref = torch.from_numpy(g5[f"grad/{n}"])
                 assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-9, n
-            # full-chain check on gradient VECTORS of parameters spread over the depth (golden: float16, max-normalised)
-            named = dict(model.named_parameters())
-            vec_names = [k[len("grad16/"):] for k in g5.files if k.startswith("grad16/")]
-            assert len(vec_names) >= 10
-            cos = {}
-            for n in vec_names:
-                ref = torch.from_numpy(g5[f"grad16/{n}"].astype(np.float32)).flatten().double() * float(g5[f"grad16scale/{n}"])
-                got = named[n].grad.detach().cpu().flatten().double()
-                cos[n] = float(torch.dot(got, ref) / (got.norm() * ref.norm()))
-                nr = float(got.norm() / ref.norm())
-                assert abs(nr - 1) <= 2e-2, (n, nr)
-            worst = min(cos, key=cos.get)
-            assert cos[worst] >= 1 - 1e-4, (worst, cos[worst], cos)
+            # full-chain check on gradient VECTORS of parameters spread over the depth (training-mode BatchNorm)
+            rep = _grad_report(g5, dict(model.named_parameters()), "grad16")
+            print("train-mode 1 - cosine / norm ratio:", {n: (f"{a:.1e}", round(b, 4)) for n, (a, b) in rep.items()})
+            assert max(a for a, _ in rep.values()) <= 1 - COS_BAR_TRAIN and \
+                max(abs(b - 1) for _, b in rep.values()) <= 1e-1, rep
             for n in ("conv0p1s1.kernel", "bn0.bn.weight"):
                 got = dict(model.named_parameters())[n].grad.cpu()
                 ref = torch.from_numpy(g5[f"grad/{n}"])
