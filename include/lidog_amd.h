@@ -73,6 +73,10 @@ int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const uint64_t *i
 int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t K, int64_t *k_off_dev,
                            int32_t *pair_in, int32_t *pair_out, int32_t *pos_out, int32_t *pos_in, int32_t *ws,
                            void *stream);
+/* Per-row lists of a rule book: row_ptr [n+1], row_list [P] = the pair positions of row o (entries of pos [K][n] that
+ * are >= 0) in ascending offset order; what lidog_sconv_reduce_rows[_stats] walk.  ws: ceil((n+1)/1024)+1 ints. */
+int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t *row_ptr, int32_t *row_list, int32_t *ws,
+                          void *stream);
 
 /* ------------------------------------------------------------------ sparse convolution
  * Replaces ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward and backward
@@ -101,6 +105,14 @@ int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C);
 int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C, const float *bias,
                              float *out, double *sums, double *partial_ws, double count, float eps, float momentum,
                              float *mean, float *invstd, float *running_mean, float *running_var, void *stream);
+/* The same two reductions over the per-row lists of lidog_kernel_map_rows (only the offsets a voxel really has are
+ * read; same additions in the same order: bit-identical results). */
+int lidog_sconv_reduce_rows(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n, int32_t C,
+                            const float *bias, const float *addend, float *out, void *stream);
+int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
+                                  int32_t C, const float *bias, float *out, double *sums, double *partial_ws,
+                                  double count, float eps, float momentum, float *mean, float *invstd,
+                                  float *running_mean, float *running_var, void *stream);
 /* count / eps / momentum / mean / invstd / running_*: as for lidog_bn_stats below (the last kernel of the
  * reduction also stores the row count behind the sums and, when mean != NULL, finalises the statistics). */
 

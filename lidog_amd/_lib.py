@@ -25,6 +25,9 @@ SIGNATURES = {
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_stats_ws": [_i64, _i32],
     "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
+    "lidog_kernel_map_rows": [_p, _i64, _i32, _p, _p, _p, _p],
+    "lidog_sconv_reduce_rows": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p],
+    "lidog_sconv_reduce_rows_stats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
     "lidog_sconv_os_block_rows": [],
     "lidog_sconv_os_segments": [_p, _p, _i32, _i64, _p, _p],

@@ -426,3 +426,42 @@ extern "C" int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ per-row lists of the rule book (for the reduction)
+// pos [K][n] (pair position of (offset k, row o) or -1) -> row_ptr [n+1], row_list [P]: the pair positions of row o in
+// ascending offset order.  The reduction pass then reads exactly the product rows a voxel has (4.3 on average for a
+// 3^3 kernel on LiDAR surfaces) instead of probing all K offsets (27 index loads and 27 row loads per voxel, 84 % of
+// them for missing neighbours).
+__global__ __launch_bounds__(256) void k_rows_count(const int32_t *__restrict__ pos, int64_t n, int K,
+                                                    int32_t *__restrict__ row_ptr) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o > n) return;
+    int c = 0;
+    if (o < n)
+        for (int k = 0; k < K; ++k) c += pos[(int64_t)k * n + o] >= 0;
+    row_ptr[o] = c;   // row_ptr[n] = 0: the exclusive scan leaves the total there
+}
+
+__global__ __launch_bounds__(256) void k_rows_fill(const int32_t *__restrict__ pos, int64_t n, int K,
+                                                   const int32_t *__restrict__ row_ptr,
+                                                   int32_t *__restrict__ row_list) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    int p = row_ptr[o];
+    for (int k = 0; k < K; ++k) {
+        const int v = pos[(int64_t)k * n + o];
+        if (v >= 0) row_list[p++] = v;
+    }
+}
+
+// ws: ceil((n + 1) / 1024) + 1 ints
+extern "C" int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t *row_ptr, int32_t *row_list,
+                                     int32_t *ws, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(n >= 0 && K >= 1 && n < ((int64_t)1 << 31) - 2, "kernel_map_rows: bad sizes");
+    k_rows_count<<<(unsigned)cdiv64(n + 1, 256), 256, 0, st>>>(pos, n, K, row_ptr);
+    if (device_exclusive_scan(row_ptr, n + 1, ws, st)) return 1;
+    if (n) k_rows_fill<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(pos, n, K, row_ptr, row_list);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}

@@ -443,6 +443,129 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__res
     }
 }
 
+// ---- the same reductions over per-row lists (lidog_kernel_map_rows): out row o = sum of T[row_list[p]] for
+// p in [row_ptr[o], row_ptr[o+1]), i.e. over the offsets the voxel really has, in ascending offset order -- the same
+// additions in the same order as the table walk above (a missing neighbour added an exact 0 there), so the results are
+// bit-identical.  Loads in unconditional batches of 4 (index clamped to the row's last entry: an L1 hit).
+__device__ __forceinline__ float4 reduce_row_list(const float4 *__restrict__ T, const int32_t *__restrict__ row_ptr,
+                                                  const int32_t *__restrict__ row_list, int C4, int64_t o, int c4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int b = row_ptr[o], e = row_ptr[o + 1];
+    for (int p = b; p < e; p += 4) {
+        int idx[4];
+        float4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) idx[j] = row_list[p + j < e ? p + j : e - 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = T[(int64_t)idx[j] * C4 + c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = p + j < e;
+            acc.x += ok ? t[j].x : 0.f;
+            acc.y += ok ? t[j].y : 0.f;
+            acc.z += ok ? t[j].z : 0.f;
+            acc.w += ok ? t[j].w : 0.f;
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_sconv_reduce_rows4(const float4 *__restrict__ T,
+                                                            const int32_t *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ row_list, int64_t n, int C4,
+                                                            const float4 *__restrict__ bias,
+                                                            const float4 *__restrict__ addend,
+                                                            float4 *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * C4) return;
+    int64_t o = idx / C4;
+    int c4 = (int)(idx % C4);
+    float4 acc = reduce_row_list(T, row_ptr, row_list, C4, o, c4);
+    if (bias) {
+        float4 b = bias[c4];
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    if (addend) {
+        float4 a = addend[idx];
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    out[idx] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *__restrict__ T,
+                                                                  const int32_t *__restrict__ row_ptr,
+                                                                  const int32_t *__restrict__ row_list, int64_t n,
+                                                                  int C4, const float4 *__restrict__ bias,
+                                                                  float4 *__restrict__ out,
+                                                                  double *__restrict__ partial) {
+    __shared__ double red[256 * 8];
+    const int RB = 256 / C4;
+    const int tid = threadIdx.x;
+    const int r = tid / C4, c4 = tid % C4;
+    const bool active = r < RB;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += (int64_t)gridDim.x * RB) {
+            float4 acc = reduce_row_list(T, row_ptr, row_list, C4, o, c4);
+            if (bias) {
+                float4 b = bias[c4];
+                acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+            }
+            out[o * C4 + c4] = acc;
+            a[0] += acc.x; a[1] += acc.y; a[2] += acc.z; a[3] += acc.w;
+            a[4] += (double)acc.x * acc.x; a[5] += (double)acc.y * acc.y;
+            a[6] += (double)acc.z * acc.z; a[7] += (double)acc.w * acc.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
+    __syncthreads();
+    if (active && r == 0) {
+        const int C = C4 * 4;
+        for (int rr = 1; rr < RB; ++rr)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
+        double *dst = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[c4 * 4 + j] = a[j];
+            dst[C + c4 * 4 + j] = a[4 + j];
+        }
+    }
+}
+
+extern "C" int lidog_sconv_reduce_rows(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
+                                       int32_t C, const float *bias, const float *addend, float *out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    LIDOG_REQUIRE(C % 4 == 0 && C >= 4, "sconv_reduce_rows: C must be a multiple of 4");
+    const int C4 = C / 4;
+    k_sconv_reduce_rows4<<<(unsigned)cdiv64(n * C4, 256), 256, 0, st>>>((const float4 *)T, row_ptr, row_list, n, C4,
+                                                                        (const float4 *)bias, (const float4 *)addend,
+                                                                        (float4 *)out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
+                                             int32_t C, const float *bias, float *out, double *sums,
+                                             double *partial_ws, double count, float eps, float momentum, float *mean,
+                                             float *invstd, float *running_mean, float *running_var, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconv_reduce_rows_stats: C must be a multiple of 4, <= 1024");
+    LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_reduce_rows_stats: finalising needs the row count");
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
+    int C4 = C / 4, RB = 256 / C4;
+    int64_t nb = cdiv64(n, (int64_t)RB * 4);
+    if (nb > 2048) nb = 2048;
+    k_sconv_reduce_rows4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, row_ptr, row_list, n, C4,
+                                                             (const float4 *)bias, (float4 *)out, partial_ws);
+    BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
+    lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 // Cin == 1 (the 5^3 stem): no product rows at all.  out[o] = sum over k ascending of x[nbr[k][o]] * W[k][:] straight from
 // the neighbour table (a product row of the two-pass path is fmaf(x, w, 0) = x * w, added in the same order: same
 // bits).  One thread per output row (consecutive lanes read consecutive entries of a table row), all C4 <= 16

@@ -101,6 +101,21 @@ class KernelMap:
         self.P = int(k_off_host[-1])
         self.pair_in, self.pair_out, self.pos_out, self.pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
         self.tiles, self.n_tiles = tiles if tiles is not None else _tiles(k_off_host, pair_in.device)
+        self._rows = {}
+
+    def rows(self, side):
+        """(row_ptr int32 [n+1], row_list int32 [P]) of the output ("out") or input ("in") rows: the pair positions
+        of every row in ascending offset order -- what the reduction pass walks (include/lidog_amd.h:
+        lidog_kernel_map_rows).  Built with the map when it is prepared ahead of time, else on first use."""
+        if side not in self._rows:
+            pos, n = (self.pos_out, self.n_out) if side == "out" else (self.pos_in, self.n_in)
+            dev = pos.device
+            row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            row_list = torch.empty(max(self.P, 1), dtype=torch.int32, device=dev)
+            ws = torch.empty((n + 1 + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
+            call("lidog_kernel_map_rows", ptr(pos), n, self.K, ptr(row_ptr), ptr(row_list), ptr(ws))
+            self._rows[side] = (row_ptr, row_list)
+        return self._rows[side]
 
 
 class _IdentityMap:
@@ -407,7 +422,14 @@ class CoordinateManager:
     def _kernel_map_finish(self, pd, k_off_host, tiles):
         K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr = pd
         P = int(k_off_host[-1])
-        return KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr, tiles)
+        m = KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr, tiles)
+        # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient; 2^3 stride 2:
+        # the strided convolution's forward and the transposed convolution's data gradient, both over the coarse rows)
+        if K == 27:
+            self._own(*m.rows("out"), *m.rows("in"))
+        elif K == 8:
+            self._own(*m.rows("out"))
+        return m
 
     def identity_map(self, n):
         if n not in self.identity:
@@ -671,20 +693,25 @@ class _SparseConvFn(torch.autograd.Function):
         else:
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
             _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
+            if Cout % 4 == 0:
+                row_ptr, row_list = m.rows("in" if swap else "out")
             if stats is not None and Cout % 4 == 0 and Cout <= 1024:
                 dev = x.device
                 sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
                 ws = torch.empty(_lib.load().lidog_sconv_reduce_stats_ws(n_out, Cout), dtype=torch.float64, device=dev)
                 if stats.sync:   # the sums (and the row count behind them) still have to be all-reduced
-                    call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
-                         ptr(ws), float(n_out), 0.0, 0.0, None, None, None, None)
+                    call("lidog_sconv_reduce_rows_stats", ptr(T), ptr(row_ptr), ptr(row_list), n_out, Cout, ptr(bias),
+                         ptr(out), ptr(sums), ptr(ws), float(n_out), 0.0, 0.0, None, None, None, None)
                 else:            # local BatchNorm: mean / invstd / running statistics finalised in the same launch
                     stats.mean = torch.empty(Cout, dtype=torch.float32, device=dev)
                     stats.invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
-                    call("lidog_sconv_reduce_stats", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), ptr(out), ptr(sums),
-                         ptr(ws), float(n_out), stats.eps, stats.momentum, ptr(stats.mean), ptr(stats.invstd),
-                         ptr(stats.running_mean), ptr(stats.running_var))
+                    call("lidog_sconv_reduce_rows_stats", ptr(T), ptr(row_ptr), ptr(row_list), n_out, Cout, ptr(bias),
+                         ptr(out), ptr(sums), ptr(ws), float(n_out), stats.eps, stats.momentum, ptr(stats.mean),
+                         ptr(stats.invstd), ptr(stats.running_mean), ptr(stats.running_var))
                 stats.sums = sums
+            elif Cout % 4 == 0:
+                call("lidog_sconv_reduce_rows", ptr(T), ptr(row_ptr), ptr(row_list), n_out, Cout, ptr(bias), None,
+                     ptr(out))
             else:
                 call("lidog_sconv_reduce", ptr(T), ptr(pos_o), n_out, K, Cout, ptr(bias), None, ptr(out))
         ctx.save_for_backward(x, W3)
@@ -753,7 +780,12 @@ class _SparseConvFn(torch.autograd.Function):
                 if ctx.needs_input_grad[1] and behind:
                     gW = queue_wgrad()
                 add = gskip if (gskip is not None and Cin % 4 == 0) else None
-                call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, ptr(add), ptr(gx))
+                if Cin % 4 == 0:
+                    row_ptr, row_list = m.rows("out" if swap else "in")
+                    call("lidog_sconv_reduce_rows", ptr(T), ptr(row_ptr), ptr(row_list), n_in, Cin, None, ptr(add),
+                         ptr(gx))
+                else:
+                    call("lidog_sconv_reduce", ptr(T), ptr(pos_i), n_in, K, Cin, None, None, ptr(gx))
                 if add is not None:
                     gskip = None
         if ctx.needs_input_grad[1] and gW is None:
