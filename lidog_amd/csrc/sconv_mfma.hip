@@ -60,8 +60,11 @@ __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
 
 // ------------------------------------------------------------------ gathered GEMM
 // Tile 128 pair-rows x 32*NT columns; wave w owns rows [32w, 32w+32) and all NT column tiles.
+#ifndef MG_MIN_WAVES
+#define MG_MIN_WAVES 1
+#endif
 template <int NT>
-__global__ __launch_bounds__(256) void k_sconv_gemm_mfma(const float *__restrict__ A,
+__global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const float *__restrict__ A,
                                                          const int32_t *__restrict__ gather,
                                                          const float *__restrict__ B,
                                                          const float *__restrict__ bias,

@@ -697,7 +697,8 @@ class _SparseConvFn(torch.autograd.Function):
                 row_ptr, row_list = m.rows("in" if swap else "out")
             if stats is not None and Cout % 4 == 0 and Cout <= 1024:
                 dev = x.device
-                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
+                sums = stats.sums_out if stats.sums_out is not None else \
+                    torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
                 ws = torch.empty(_lib.load().lidog_sconv_reduce_stats_ws(n_out, Cout), dtype=torch.float64, device=dev)
                 if stats.sync:   # the sums (and the row count behind them) still have to be all-reduced
                     call("lidog_sconv_reduce_rows_stats", ptr(T), ptr(row_ptr), ptr(row_list), n_out, Cout, ptr(bias),
@@ -809,7 +810,8 @@ def _bn_ws(C, hw, dev):
 class StatsRequest:
     """What a convolution needs to know to produce the statistics of the BatchNorm that follows it in the
     epilogue of its reduction pass (conv_bn), and where it leaves them."""
-    __slots__ = ("eps", "momentum", "running_mean", "running_var", "sync", "sums", "mean", "invstd")
+    __slots__ = ("eps", "momentum", "running_mean", "running_var", "sync", "sums", "mean", "invstd", "sums_out",
+                 "presynced")
 
     def __init__(self, bn, sync, momentum):
         self.eps = float(bn.eps)
@@ -817,6 +819,8 @@ class StatsRequest:
         self.running_mean, self.running_var = bn.running_mean, bn.running_var
         self.sync = sync
         self.sums = self.mean = self.invstd = None
+        self.sums_out = None      # where the (sum x, sum x^2, rows) vector goes (a slice of a joint all-reduce buffer)
+        self.presynced = False    # the sums have been all-reduced already (together with another layer's)
 
 
 class _BatchNormFn(torch.autograd.Function):
@@ -841,7 +845,7 @@ class _BatchNormFn(torch.autograd.Function):
         count = rows
         dev = x.device
         if training:
-            sums, mean, invstd = pre if pre is not None else (None, None, None)
+            sums, mean, invstd, presynced = pre if pre is not None else (None, None, None, False)
             sync = group is not None
             if sums is None:
                 sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
@@ -854,9 +858,10 @@ class _BatchNormFn(torch.autograd.Function):
                     call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)), rows, float(eps),
                          float(momentum), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var))
             if sync:
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=group)   # (sum x, sum x^2, rows) in ONE message
-                count = -1.0                          # consumers read the global count from sums[2C]
+                if not presynced:
+                    import torch.distributed as dist
+                    dist.all_reduce(sums, group=group)   # (sum x, sum x^2, rows) in ONE message
+                count = -1.0                              # consumers read the global count from sums[2C]
             if mean is None:
                 mean = torch.empty(C, dtype=torch.float32, device=dev)
                 invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -943,7 +948,8 @@ def batch_norm(x, bn, hw=1, relu=False, residual=None, group=None, stats=None):
         momentum = stats.momentum
     else:
         momentum = _training_momentum(bn) if training else 0.0
-    pre = (stats.sums, stats.mean, stats.invstd) if (training and stats is not None and stats.sums is not None) else None
+    pre = (stats.sums, stats.mean, stats.invstd, stats.presynced) \
+        if (training and stats is not None and stats.sums is not None) else None
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps,
                               hw, relu, residual, group, pre)
 
@@ -1206,6 +1212,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        group = self.norm1._sync_group() if self.norm1.bn.training else None
+        if group is not None and isinstance(self.downsample, nn.Sequential) and len(self.downsample) == 2 and \
+                isinstance(self.downsample[1], MinkowskiSyncBatchNorm) and self.downsample[1].bn.training:
+            return self._forward_joint_sync(x, group)
         if x.F.requires_grad:
             # the residual branch takes x from conv1's autograd node, so the two gradients of x (conv1's data
             # gradient and the residual's / the downsample convolution's) are summed by conv1's reduction pass, not
@@ -1214,6 +1224,35 @@ class BasicBlock(nn.Module):
         else:
             out = conv_bn(self.conv1, self.norm1, x, relu=True)
         residual = x if self.downsample is None else self.downsample(x)
+        return conv_bn(self.conv2, self.norm2, out, relu=True, residual=residual)
+
+    def _forward_joint_sync(self, x, group):
+        """First block of a layer under SyncBatchNorm: conv1 and the 1x1 downsample convolution both read x and are
+        independent, so the statistics of their two BatchNorms travel in ONE all-reduce (7 collectives fewer per
+        forward pass; a statistics all-reduce is pure latency on the dependent chain)."""
+        import torch.distributed as dist
+        bn1, (convd, bnd) = self.norm1, self.downsample
+        Ca, Cd = bn1.bn.num_features, bnd.bn.num_features
+        joint = torch.empty(2 * Ca + 1 + 2 * Cd + 1, dtype=torch.float64, device=x.F.device)
+        req_a = StatsRequest(bn1.bn, True, _training_momentum(bn1.bn))
+        req_d = StatsRequest(bnd.bn, True, _training_momentum(bnd.bn))
+        req_a.sums_out, sums_d = joint[:2 * Ca + 1], joint[2 * Ca + 1:]
+        if x.F.requires_grad:
+            y1, x = self.conv1(x, stats=req_a, skip=True)
+        else:
+            y1 = self.conv1(x, stats=req_a)
+        yd = convd(x)
+        if req_a.sums is None:     # conv1 did not go through the reduction pass with fused statistics
+            call("lidog_bn_stats", ptr(y1.F), y1.F.shape[0], Ca, 1, ptr(req_a.sums_out), ptr(_bn_ws(Ca, 1, y1.F.device)),
+                 float(y1.F.shape[0]), 0.0, 0.0, None, None, None, None)
+            req_a.sums = req_a.sums_out
+        call("lidog_bn_stats", ptr(yd.F), yd.F.shape[0], Cd, 1, ptr(sums_d), ptr(_bn_ws(Cd, 1, yd.F.device)),
+             float(yd.F.shape[0]), 0.0, 0.0, None, None, None, None)
+        req_d.sums = sums_d
+        dist.all_reduce(joint, group=group)
+        req_a.presynced = req_d.presynced = True
+        out = bn1(y1, relu=True, stats=req_a)
+        residual = bnd(yd, stats=req_d)
         return conv_bn(self.conv2, self.norm2, out, relu=True, residual=residual)
 
 

@@ -82,16 +82,20 @@ class GradientBuckets:
     contiguous slices walked from the END of the buffer.  xGMI is point-to-point (7 links per GPU):
     a few large messages (default 32 MiB) keep every link busy without paying per-message latency.
 
-    A bucket is reduced as soon as its last gradient has been produced.  The collectives run on a communicator of
-    their own (`dist.new_group`): RCCL executes the collectives of ONE communicator in issue order on one stream, so
-    a 32 MiB bucket on the SyncBatchNorm communicator would sit in front of every later statistics all-reduce of the
-    data-gradient chain.  With the second backward stream active (me._WgradLane) the bucket's weight gradients may
-    still be running there: the collective is issued from THAT stream (RCCL's stream then waits for the lane, which
-    itself waits for everything queued on the main stream so far) and the main stream never waits before finish()."""
+    A bucket is reduced as soon as its last gradient has been produced.  With the second backward stream active
+    (me._WgradLane) the bucket's weight gradients may still be running there: the collective is issued from THAT
+    stream (RCCL's stream then waits for the lane, which itself waits for everything queued on the main stream so far)
+    and the main stream never waits before finish().
+    RCCL executes the collectives of ONE communicator in issue order on one stream, so a bucket that still waits for
+    the lane holds back the SyncBatchNorm statistics all-reduces issued after it -- by at most the lane's lag of about
+    one layer.  `LIDOG_GRAD_COMM=own` gives the buckets a communicator of their own (`dist.new_group`) and removes
+    that coupling; it is not the default because two communicators in flight at once could not be exercised on more
+    than one rank in this build's environment, and a same-communicator schedule is identical on every rank by
+    construction."""
 
     single_rank = False   # test hook: bucket and all-reduce even in a one-rank process group
 
-    def __init__(self, flat, group=None, bucket_bytes=32 << 20, own_communicator=True, local=False):
+    def __init__(self, flat, group=None, bucket_bytes=32 << 20, own_communicator=None, local=False):
         """`local=True`: no data parallelism for this optimiser even inside an initialised process group"""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if (dist.is_initialized() and not local) else 1
@@ -104,6 +108,9 @@ class GradientBuckets:
         self.issued_early = 0     # buckets reduced from a gradient hook, i.e. while backward was still running
         if not self.active:
             return
+        if own_communicator is None:
+            import os
+            own_communicator = os.environ.get("LIDOG_GRAD_COMM", "shared") == "own"
         if own_communicator and group is None:
             self.group = dist.new_group(ranks=list(range(dist.get_world_size())))
         cur_lo = cur_hi = flat.total
