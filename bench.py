@@ -55,14 +55,14 @@ class GemmTimer:
         orig = me._gemm
         timer = self
 
-        def timed(A, gather, B, bias, m, Cin, Cout, out, scatter):
+        def timed(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles=None):
             if not timer.enabled:
-                return orig(A, gather, B, bias, m, Cin, Cout, out, scatter)
+                return orig(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            orig(A, gather, B, bias, m, Cin, Cout, out, scatter)
+            orig(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles)
             e1.record()
-            rows = m.P
+            rows = m.P if tiles is None else tiles[2]   # pairs this launch multiplies (the centre segment may be left out)
             # algorithmic traffic of one launch: every distinct input row and weight read once, every
             # product row written once, the gather index read once (SURVEY.md 8(d) per-layer formula)
             n_src = A.shape[0]

@@ -74,9 +74,10 @@ int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int3
                            int32_t *pair_in, int32_t *pair_out, int32_t *pos_out, int32_t *pos_in, int32_t *ws,
                            void *stream);
 /* Per-row lists of a rule book: row_ptr [n+1], row_list [P] = the pair positions of row o (entries of pos [K][n] that
- * are >= 0) in ascending offset order; what lidog_sconv_reduce_rows[_stats] walk.  ws: ceil((n+1)/1024)+1 ints. */
-int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t *row_ptr, int32_t *row_list, int32_t *ws,
-                          void *stream);
+ * are >= 0) in ascending offset order; what lidog_sconv_reduce_rows[_stats] walk.  mark_k >= 0: the entry of that
+ * offset is stored as -1 (lidog_sconv_center_reduce computes the centre offset itself).  ws: ceil((n+1)/1024)+1 ints. */
+int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t mark_k, int32_t *row_ptr,
+                          int32_t *row_list, int32_t *ws, void *stream);
 
 /* ------------------------------------------------------------------ sparse convolution
  * Replaces ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward and backward
@@ -113,6 +114,18 @@ int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_ptr, const 
                                   int32_t C, const float *bias, float *out, double *sums, double *partial_ws,
                                   double count, float eps, float momentum, float *mean, float *invstd,
                                   float *running_mean, float *running_var, void *stream);
+/* Reduction with the centre offset of a stride-1 odd kernel fused in (csrc/sconv_center.hip): out [n, Cout] = sum over
+ * the per-row lists in ascending offset order, where the entry marked -1 is A[o] . Wc (Wc [Cin, Cout] = the centre
+ * offset's weights), computed here on the matrix cores, and every other entry is a row of T (written by
+ * lidog_sconv_gemm over the rule book WITHOUT its centre segment) -- the additions of the two-pass path in the same
+ * order, bit-identical; + bias + addend.  sums != NULL: BatchNorm statistics as lidog_sconv_reduce_stats leaves them
+ * (partial_ws: lidog_sconv_center_reduce_ws(n, Cout) doubles).  Cin, Cout multiples of 32; lists of a 3^3 kernel. */
+int64_t lidog_sconv_center_reduce_ws(int64_t n, int32_t C);
+int lidog_sconv_center_reduce(const float *A, const float *Wc, const float *T, const int32_t *row_ptr,
+                              const int32_t *row_list, int64_t n, int32_t Cin, int32_t Cout, const float *bias,
+                              const float *addend, float *out, double *sums, double *partial_ws, double count,
+                              float eps, float momentum, float *mean, float *invstd, float *running_mean,
+                              float *running_var, void *stream);
 /* count / eps / momentum / mean / invstd / running_*: as for lidog_bn_stats below (the last kernel of the
  * reduction also stores the row count behind the sums and, when mean != NULL, finalises the statistics). */
 

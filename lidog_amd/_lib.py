@@ -25,7 +25,9 @@ SIGNATURES = {
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_stats_ws": [_i64, _i32],
     "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
-    "lidog_kernel_map_rows": [_p, _i64, _i32, _p, _p, _p, _p],
+    "lidog_kernel_map_rows": [_p, _i64, _i32, _i32, _p, _p, _p, _p],
+    "lidog_sconv_center_reduce_ws": [_i64, _i32],
+    "lidog_sconv_center_reduce": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows_stats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
@@ -80,7 +82,7 @@ SIGNATURES = {
     "lidog_allreduce_f64": [_p, _i64, _p, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
-             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}
+             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_sconv_center_reduce_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}
 
 _lib = None
 

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_rows_count(const int32_t *__restrict__ 
     row_ptr[o] = c;   // row_ptr[n] = 0: the exclusive scan leaves the total there
 }
 
-__global__ __launch_bounds__(256) void k_rows_fill(const int32_t *__restrict__ pos, int64_t n, int K,
+__global__ __launch_bounds__(256) void k_rows_fill(const int32_t *__restrict__ pos, int64_t n, int K, int mark_k,
                                                    const int32_t *__restrict__ row_ptr,
                                                    int32_t *__restrict__ row_list) {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -450,18 +450,19 @@ __global__ __launch_bounds__(256) void k_rows_fill(const int32_t *__restrict__ p
     int p = row_ptr[o];
     for (int k = 0; k < K; ++k) {
         const int v = pos[(int64_t)k * n + o];
-        if (v >= 0) row_list[p++] = v;
+        if (v >= 0) row_list[p++] = k == mark_k ? -1 : v;
     }
 }
 
-// ws: ceil((n + 1) / 1024) + 1 ints
-extern "C" int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t *row_ptr, int32_t *row_list,
-                                     int32_t *ws, void *stream) {
+// ws: ceil((n + 1) / 1024) + 1 ints.  mark_k >= 0: the entry of that offset is stored as -1 (the centre offset whose
+// product lidog_sconv_center_reduce computes itself), -1: every entry is a pair position.
+extern "C" int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t mark_k, int32_t *row_ptr,
+                                     int32_t *row_list, int32_t *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(n >= 0 && K >= 1 && n < ((int64_t)1 << 31) - 2, "kernel_map_rows: bad sizes");
     k_rows_count<<<(unsigned)cdiv64(n + 1, 256), 256, 0, st>>>(pos, n, K, row_ptr);
     if (device_exclusive_scan(row_ptr, n + 1, ws, st)) return 1;
-    if (n) k_rows_fill<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(pos, n, K, row_ptr, row_list);
+    if (n) k_rows_fill<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(pos, n, K, mark_k, row_ptr, row_list);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

@@ -476,7 +476,11 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4(const float4 *__rest
                                                             const float4 *__restrict__ bias,
                                                             const float4 *__restrict__ addend,
                                                             float4 *__restrict__ out) {
+#ifdef RED_EXP_REVERSE   // experiment: last rows first (their product rows were written last: still in the Infinity Cache?)
+    int64_t idx = (int64_t)(gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x;
+#else
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+#endif
     if (idx >= n * C4) return;
     int64_t o = idx / C4;
     int c4 = (int)(idx % C4);

@@ -38,11 +38,15 @@ def kernel_offsets(kernel_size, tensor_stride, dilation=1):
     return np.array([(x, y, z) for z in r for y in r for x in r], dtype=np.int32)
 
 
-def _tiles_host(k_off_host):
+def _tiles_host(k_off_host, skip_k=-1):
     """tile descriptors (tile_k, tile_row0, tile_rows) for 128-row tiles that never straddle an offset:
-    (int32 [3, n_tiles] numpy array, n_tiles)"""
+    (int32 [3, n_tiles] numpy array, n_tiles).  `skip_k`: an offset left out (the centre offset when the reduction
+    pass computes it itself, csrc/sconv_center.hip)"""
     k_off = np.asarray(k_off_host, dtype=np.int64)
     cnt = np.diff(k_off)
+    if skip_k >= 0:
+        cnt = cnt.copy()
+        cnt[skip_k] = 0
     nt = (cnt + TILE_ROWS - 1) // TILE_ROWS
     total = int(nt.sum())
     if total == 0:
@@ -59,8 +63,8 @@ def _tiles_host(k_off_host):
     return np.stack([tile_k[order], row0[order], rows[order]]).astype(np.int32), total
 
 
-def _tiles(k_off_host, device):
-    desc, total = _tiles_host(k_off_host)
+def _tiles(k_off_host, device, skip_k=-1):
+    desc, total = _tiles_host(k_off_host, skip_k)
     return torch.from_numpy(desc).to(device), total
 
 
@@ -85,6 +89,13 @@ class _Arena:
         return dev, out
 
 
+def _center_of(key):
+    """index of the centre offset of a kernel-map key (s_in, s_out, kernel size, dilation) whose centre segment is the
+    identity map (same coordinate map on both sides, odd kernel), else -1"""
+    s_in, s_out, ksize, _ = key
+    return (ksize ** 3) // 2 if (s_in == s_out and ksize % 2 == 1 and ksize > 1) else -1
+
+
 class _CoordMap:
     __slots__ = ("coords", "keys", "vals", "cap", "n")
 
@@ -102,20 +113,39 @@ class KernelMap:
         self.pair_in, self.pair_out, self.pos_out, self.pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
         self.tiles, self.n_tiles = tiles if tiles is not None else _tiles(k_off_host, pair_in.device)
         self._rows = {}
+        # centre offset of a stride-1 odd kernel: its segment of the rule book is the identity map (every voxel pairs
+        # with itself), which lets the reduction pass compute its products itself (csrc/sconv_center.hip)
+        self.center = -1
+        self._tiles_nc = None
 
-    def rows(self, side):
+    def set_center(self, k, tiles_nc=None):
+        if int(self.k_off_host[k + 1]) - int(self.k_off_host[k]) == self.n_out == self.n_in:
+            self.center = k
+            self._tiles_nc = tiles_nc
+
+    @property
+    def tiles_nc(self):
+        """(tile descriptors, tile count, pairs) of the rule book without its centre segment"""
+        if self._tiles_nc is None:
+            self._tiles_nc = _tiles(self.k_off_host, self.pair_in.device, self.center)
+        return self._tiles_nc + (self.P - self.n_out,)
+
+    def rows(self, side, mark_center=False):
         """(row_ptr int32 [n+1], row_list int32 [P]) of the output ("out") or input ("in") rows: the pair positions
         of every row in ascending offset order -- what the reduction pass walks (include/lidog_amd.h:
-        lidog_kernel_map_rows).  Built with the map when it is prepared ahead of time, else on first use."""
-        if side not in self._rows:
+        lidog_kernel_map_rows); `mark_center`: the centre offset's entry is -1.  Built with the map when it is
+        prepared ahead of time, else on first use."""
+        key = (side, mark_center)
+        if key not in self._rows:
             pos, n = (self.pos_out, self.n_out) if side == "out" else (self.pos_in, self.n_in)
             dev = pos.device
             row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
             row_list = torch.empty(max(self.P, 1), dtype=torch.int32, device=dev)
             ws = torch.empty((n + 1 + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
-            call("lidog_kernel_map_rows", ptr(pos), n, self.K, ptr(row_ptr), ptr(row_list), ptr(ws))
-            self._rows[side] = (row_ptr, row_list)
-        return self._rows[side]
+            call("lidog_kernel_map_rows", ptr(pos), n, self.K, self.center if mark_center else -1, ptr(row_ptr),
+                 ptr(row_list), ptr(ws))
+            self._rows[key] = (row_ptr, row_list)
+        return self._rows[key]
 
 
 class _IdentityMap:
@@ -296,13 +326,17 @@ class CoordinateManager:
             k_off_host = hosts[off:off + K + 1]
             off += K + 1
             desc, n_tiles = _tiles_host(k_off_host)
-            todo.append(("kmap", key, pd, k_off_host, arena.add(desc), n_tiles))
+            nc = None
+            if _center_of(key) >= 0:
+                desc_nc, n_nc = _tiles_host(k_off_host, _center_of(key))
+                nc = (arena.add(desc_nc), n_nc)
+            todo.append(("kmap", key, pd, k_off_host, arena.add(desc), n_tiles, nc))
         for key in want:
             if key[0] == "identity":
                 n = self.maps[key[1]].n
                 if n not in self.identity:
                     desc, n_tiles = _tiles_host([0, n])
-                    todo.append(("identity", n, None, [0, n], arena.add(desc), n_tiles))
+                    todo.append(("identity", n, None, [0, n], arena.add(desc), n_tiles, None))
         # weight-gradient work items of every (map, Cin, Cout) seen
         items_todo = []
         k_off_of = {t[1]: t[3] for t in todo}
@@ -324,9 +358,10 @@ class CoordinateManager:
                 items_todo.append((key, chunk, arena.add(items), total, arena.add(item_off)))
         dev, views = arena.ship(self.device)
         self._own(dev)
-        for kind, key, pd, k_off_host, slot, n_tiles in todo:
+        for kind, key, pd, k_off_host, slot, n_tiles, nc in todo:
             if kind == "kmap":
-                self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, (views[slot], n_tiles))
+                tiles_nc = (views[nc[0]], nc[1]) if nc is not None else None
+                self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, (views[slot], n_tiles), key, tiles_nc)
             else:
                 self.identity[key] = _IdentityMap(key, self.device, (views[slot], n_tiles))
                 self._own(self.identity[key].k_off, self.identity[key].rows)
@@ -393,7 +428,7 @@ class CoordinateManager:
             self.stride(s_in, s_out)
         pd = self._kernel_map_launch(key)
         k_off_host = pd[3].tolist()  # one synchronisation per kernel map on this (lazy) path
-        self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, None)
+        self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, None, key)
         return self.kmaps[key]
 
     def _kernel_map_launch(self, key):
@@ -419,14 +454,19 @@ class CoordinateManager:
         self._own(nbr, k_off, pair_in, pair_out, pos_out, pos_in)
         return (K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr)
 
-    def _kernel_map_finish(self, pd, k_off_host, tiles):
+    def _kernel_map_finish(self, pd, k_off_host, tiles, key=None, tiles_nc=None):
         K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr = pd
         P = int(k_off_host[-1])
         m = KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr, tiles)
-        # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient; 2^3 stride 2:
-        # the strided convolution's forward and the transposed convolution's data gradient, both over the coarse rows)
-        if K == 27:
-            self._own(*m.rows("out"), *m.rows("in"))
+        if key is not None and _center_of(key) >= 0:
+            m.set_center(_center_of(key), tiles_nc)
+        # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient, the centre
+        # entry marked; 2^3 stride 2: the strided convolution's forward and the transposed convolution's data
+        # gradient, both over the coarse rows)
+        if m.center >= 0 and K == 27:
+            self._own(*m.rows("out", True), *m.rows("in", True))
+            if m._tiles_nc is None:
+                self._own(m.tiles_nc[0])
         elif K == 8:
             self._own(*m.rows("out"))
         return m
@@ -587,9 +627,30 @@ def _grad_out(param, shape):
     return buf[off:off + param.numel()].view(shape)
 
 
-def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter):
-    call("lidog_sconv_gemm", ptr(A), ptr(gather), ptr(B), ptr(bias), ptr(m.tiles[0]), ptr(m.tiles[1]),
-         ptr(m.tiles[2]), m.n_tiles, Cin, Cout, ptr(out), ptr(scatter))
+def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles=None):
+    """`tiles`: (descriptors, count, pairs) of a subset of the rule book (KernelMap.tiles_nc), default all of it"""
+    desc, n_tiles = (tiles[0], tiles[1]) if tiles is not None else (m.tiles, m.n_tiles)
+    call("lidog_sconv_gemm", ptr(A), ptr(gather), ptr(B), ptr(bias), ptr(desc[0]), ptr(desc[1]), ptr(desc[2]),
+         n_tiles, Cin, Cout, ptr(out), ptr(scatter))
+
+
+def _use_center(m, Cin, Cout):
+    """the reduction pass computes the centre offset itself (csrc/sconv_center.hip): 3^3 stride-1 maps, channel counts
+    the matrix-core kernels take, matrix cores selected"""
+    return getattr(m, "center", -1) >= 0 and m.K == 27 and Cin % 32 == 0 and Cout % 32 == 0 and \
+        _CENTER_FUSED and m.n_out >= _CENTER_MIN_ROWS and min(Cin, Cout) >= _CENTER_MIN_CH and \
+        _lib.load().lidog_get_sparse_core() == 1
+
+
+# Measured on MI355X (scripts/bench_pair.py): the saving is the centre segment's product rows (written + read: 23 % of
+# T at stride 1), the price is that the list walk runs in a register-heavy matrix-core kernel with a third of the
+# waves of the stand-alone reduction.  GEMM + reduction back to back: stride-1 layers with >= 96 channels 1.12-1.14 x,
+# stride 2 / 96 channels 1.02 x, narrower or deeper layers 0.78-0.99 x.  In the full training step (weight gradients
+# co-running on the second stream) the difference vanishes: 50.54 vs 50.57 ms per step, twice.  OFF by default;
+# LIDOG_CENTER_FUSED=1 turns it on for the layers above the two thresholds (results are bit-identical either way).
+_CENTER_FUSED = os.environ.get("LIDOG_CENTER_FUSED", "0") == "1"
+_CENTER_MIN_ROWS = int(os.environ.get("LIDOG_CENTER_MIN_ROWS", "250000"))
+_CENTER_MIN_CH = int(os.environ.get("LIDOG_CENTER_MIN_CH", "96"))
 
 
 _WGRAD_TARGET_BLOCKS = 2048   # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X
@@ -692,10 +753,30 @@ class _SparseConvFn(torch.autograd.Function):
             call("lidog_sconv_cin1", ptr(x), ptr(m.nbr), ptr(W3), ptr(bias), n_out, K, Cout, ptr(out))
         else:
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
-            _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
+            center = not swap and _use_center(m, Cin, Cout)
+            _gemm(x, g_in, W3, None, m, Cin, Cout, T, None, m.tiles_nc if center else None)
             if Cout % 4 == 0:
-                row_ptr, row_list = m.rows("in" if swap else "out")
-            if stats is not None and Cout % 4 == 0 and Cout <= 1024:
+                row_ptr, row_list = m.rows("in" if swap else "out", center)
+            if center:
+                # reduction with the centre offset's products computed in place (no product rows for it)
+                dev = x.device
+                want = stats is not None and Cout <= 1024
+                sums = ws = None
+                fin = (float(n_out), 0.0, 0.0, None, None, None, None)
+                if want:
+                    sums = stats.sums_out if stats.sums_out is not None else \
+                        torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
+                    ws = torch.empty(_lib.load().lidog_sconv_center_reduce_ws(n_out, Cout), dtype=torch.float64,
+                                     device=dev)
+                    if not stats.sync:
+                        stats.mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+                        stats.invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+                        fin = (float(n_out), stats.eps, stats.momentum, ptr(stats.mean), ptr(stats.invstd),
+                               ptr(stats.running_mean), ptr(stats.running_var))
+                    stats.sums = sums
+                call("lidog_sconv_center_reduce", ptr(x), ptr(W3[m.center]), ptr(T), ptr(row_ptr), ptr(row_list), n_out,
+                     Cin, Cout, ptr(bias), None, ptr(out), ptr(sums), ptr(ws), *fin)
+            elif stats is not None and Cout % 4 == 0 and Cout <= 1024:
                 dev = x.device
                 sums = stats.sums_out if stats.sums_out is not None else \
                     torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
@@ -777,11 +858,17 @@ class _SparseConvFn(torch.autograd.Function):
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, gx, g_in)
             else:
                 T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
-                _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
+                center = not swap and _use_center(m, Cout, Cin)
+                _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None, m.tiles_nc if center else None)
                 if ctx.needs_input_grad[1] and behind:
                     gW = queue_wgrad()
                 add = gskip if (gskip is not None and Cin % 4 == 0) else None
-                if Cin % 4 == 0:
+                if center:
+                    row_ptr, row_list = m.rows("in", True)
+                    call("lidog_sconv_center_reduce", ptr(gout), ptr(Wt[m.center]), ptr(T), ptr(row_ptr), ptr(row_list),
+                         n_in, Cout, Cin, None, ptr(add), ptr(gx), None, None, float(n_in), 0.0, 0.0, None, None, None,
+                         None)
+                elif Cin % 4 == 0:
                     row_ptr, row_list = m.rows("out" if swap else "in")
                     call("lidog_sconv_reduce_rows", ptr(T), ptr(row_ptr), ptr(row_list), n_in, Cin, None, ptr(add),
                          ptr(gx))
