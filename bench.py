@@ -154,7 +154,7 @@ def main():
     import lidog_amd
     import lidog_amd.me as ME
     from lidog_amd import synth
-    from lidog_amd.trainer import FlatAdam, LiDOGStep, setup_data_parallel
+    from lidog_amd.train import build_model, build_step
 
     if single_dp:
         from lidog_amd.trainer import GradientBuckets
@@ -163,12 +163,11 @@ def main():
     if not args.no_kernel_timing:
         timer.wrap(ME)
 
+    # model, SyncBN + data-parallel wiring, optimiser and step object come from the owning driver (lidog_amd/train.py,
+    # the restatement of train_lidog.py:42-75,227-231 and trainer_lighting_2d.py:349-360); this file only times steps
     torch.manual_seed(1234)  # pipeline.seed of configs/lidog/single/semantickitti.yaml
-    model = lidog_amd.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5,
-                                    decoder_2d_level=["block8"], mapping_bound_2d=50.0).cuda()
-    model = setup_data_parallel(model)
-    model.train()
-    step = LiDOGStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4), source_weights=(0.5, 0.5))
+    model, step, _ = build_step(build_model("MinkUNet34BEV", bound_2d=50.0), "MinkUNet34BEV", optimizer="Adam", lr=1e-3,
+                                weight_decay=1e-4, source_weights=(0.5, 0.5))
 
     # two distinct batches per rank, resident in HBM, cycled (scan seeds differ per rank)
     base = rank * 2 * args.batch
