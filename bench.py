@@ -44,7 +44,7 @@ def parse():
 
 
 class GemmTimer:
-    """HIP events around every launch of the dominant kernel (the gathered GEMM of csrc/sconv.hip), on the
+    """HIP events around every launch of the dominant kernel (the gathered GEMM, csrc/sconv_mfma.hip), on the
     stream it is launched on, with its algorithmic bytes/FLOPs."""
 
     def __init__(self):

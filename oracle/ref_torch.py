@@ -2,8 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/me_oracle.c header).  These functions
 restate reference code that cannot travel to the GPU box; each one is checked
-bit-for-bit against the reference function itself in the build container
-(tests/test_oracle_vs_reference.py) and through tests/golden/*.npz.
+against golden vectors the reference function itself produced in the build
+container (tests/golden/make_golden.py -> tests/golden/*.npz, tests/test_oracle_cpu.py).
 
   sparse2super_ref   utils/models/minkunet_bev.py:158-230 (filter_bounds + sparse2super)
   Encoder2DRef       utils/models/conv2d.py:9-25,42-52,113-119,180-197
