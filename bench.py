@@ -248,8 +248,10 @@ def main():
         res = {"metric": "LiDAR scans/sec, MinkUNet34+BEV training step @120k pts", "value": value, "unit": "scans/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{n_vox:.0f} voxels/scan ({args.config} synthetic, 0.05 m), MinkUNet34+BEV B=50 "
-                                      f"train step (configs[1]), bs={args.batch}/GPU, SoftDICE+DICE, Adam",
+               "config": {"workload": f"{n_vox:.0f} voxels/scan ({args.config} synthetic, {synth.CONFIGS[args.config]['voxel']} m), "
+                                      f"MinkUNet34+BEV B=50 train step"
+                                      f"{' (configs[1])' if (args.config, args.batch) == ('kitti120k', 4) else ''}, "
+                                      f"bs={args.batch}/GPU, SoftDICE+DICE, Adam",
                           "voxels_per_scan": n_vox, "seed0_stride_counts": seed0_counts,
                           "global_batch": world * args.batch,
                           "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else "")},
