@@ -137,6 +137,16 @@ def call(name, *args):
         raise RuntimeError(f"{name} failed ({rc}): {load().lidog_last_error().decode()}")
 
 
+def call_on(raw_stream, name, *args):
+    """the same on an explicit hipStream_t (a stream's .cuda_stream): no switch of torch's current stream"""
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args, raw_stream)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {load().lidog_last_error().decode()}")
+
+
 def require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError(f"lidog_amd: {what} must live on the GPU (got {t.device}); there is no CPU path")

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, call_on, ptr
 
 TILE_ROWS = 128  # GM_TM of csrc/sconv.hip
 
@@ -198,6 +198,7 @@ class _WgradLane:
     def __init__(self, device):
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
+        self.raw = self.stream.cuda_stream    # hipStream_t: kernels are launched on it without switching torch's stream
         self.keep = []
         self.pending = False
 
@@ -830,16 +831,19 @@ class _SparseConvFn(torch.autograd.Function):
             items, n_items, item_off = _wgrad_items(m, Cin, Cout)
             slabs = _lib.load().lidog_sconv_wgrad_slabs(Cin, Cout, n_items)
 
-            def wgrad(gW):
-                partial = torch.empty((max(slabs, 1), Cin, Cout), dtype=torch.float32, device=x.device)
-                call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items,
-                     ptr(item_off), K, Cin, Cout, ptr(partial), ptr(gW))
+            partial = torch.empty((max(slabs, 1), Cin, Cout), dtype=torch.float32, device=x.device)
             if gW is not None and lane_on:
-                with torch.cuda.stream(_WgradLane.get(x.device).fork(x, gout, m)):
-                    wgrad(gW)
+                # launched on the lane's raw stream (no switch of torch's current stream: 2 x ~10 us of host time per
+                # convolution); the scratch comes from the main stream's pool and is kept alive until the join, and
+                # the lane has just been made to wait for everything queued on the main stream (fork)
+                lane = _WgradLane.get(x.device)
+                lane.fork(x, gout, m, partial)
+                call_on(lane.raw, "lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items,
+                        ptr(item_off), K, Cin, Cout, ptr(partial), ptr(gW))
             else:
                 gW = gW if gW is not None else torch.empty_like(W3)
-                wgrad(gW)
+                call("lidog_sconv_wgrad", ptr(x), ptr(g_in), ptr(gout), ptr(g_out), ptr(items), n_items,
+                     ptr(item_off), K, Cin, Cout, ptr(partial), ptr(gW))
             return gW.view(ctx.w_shape)
 
         if ctx.needs_input_grad[1] and not behind:
