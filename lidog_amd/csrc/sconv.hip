@@ -1077,6 +1077,16 @@ __global__ __launch_bounds__(256) void k_transpose_batched(const float *__restri
     const int ci0 = (r / tco) * 32, co0 = (r % tco) * 32;
     const float *W = src + s_d[0] + (size_t)k * Cin * Cout;
     float *Wt = dst + s_d[1] + (size_t)k * Cin * Cout;
+    if ((Cin & 31) == 0 && (Cout & 31) == 0 && (((uintptr_t)W | (uintptr_t)Wt) & 15) == 0) {
+        // full tile, 16-byte accesses both ways: thread (row = t >> 3, quad = t & 7) moves one float4 in and one out
+        const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+        const float4 v = *reinterpret_cast<const float4 *>(W + (size_t)(ci0 + r) * Cout + co0 + 4 * q);
+        tile[r][4 * q] = v.x; tile[r][4 * q + 1] = v.y; tile[r][4 * q + 2] = v.z; tile[r][4 * q + 3] = v.w;
+        __syncthreads();
+        const float4 o = make_float4(tile[4 * q][r], tile[4 * q + 1][r], tile[4 * q + 2][r], tile[4 * q + 3][r]);
+        *reinterpret_cast<float4 *>(Wt + (size_t)(co0 + r) * Cin + ci0 + 4 * q) = o;
+        return;
+    }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int rr = ty; rr < 32; rr += 8)
         if (ci0 + rr < Cin && co0 + tx < Cout) tile[rr][tx] = W[(size_t)(ci0 + rr) * Cout + co0 + tx];
