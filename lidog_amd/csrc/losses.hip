@@ -69,17 +69,27 @@ __global__ __launch_bounds__(256) void k_dice_sums(const float *__restrict__ log
 
 // one block: sums[4C] over the partials in block order; loss; coef[2C] = (a_c, b_c) with
 // d loss / d p_rc = a_c * t_rc + b_c * (2 p_rc or 1)
-__global__ __launch_bounds__(64) void k_dice_finish(const double *__restrict__ partial, int nb, int C, int use_tmask,
-                                                    float offset, float *__restrict__ loss, float *__restrict__ coef) {
+__global__ __launch_bounds__(512) void k_dice_finish(const double *__restrict__ partial, int nb, int C, int use_tmask,
+                                                     float offset, float *__restrict__ loss, float *__restrict__ coef) {
+    // 8 lanes per column: lane l adds the partials b = l, l + 8, ...; the 8 lane sums are combined in lane order
+    // (fixed order: bit-reproducible).  One thread per column took 56 us on the step's forward -> backward seam.
     __shared__ double s[4 * DL_MAXC];
-    const int i = threadIdx.x;
+    __shared__ double part[8][4 * DL_MAXC];
+    const int i = threadIdx.x >> 3, l = threadIdx.x & 7;
     if (i < 4 * C) {
         double v = 0;
-        for (int b = 0; b < nb; ++b) v += partial[(size_t)b * 4 * C + i];
+        for (int b = l; b < nb; b += 8) v += partial[(size_t)b * 4 * C + i];
+        part[l][i] = v;
+    }
+    __syncthreads();
+    if (l == 0 && i < 4 * C) {
+        double v = part[0][i];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v += part[q][i];
         s[i] = v;
     }
     __syncthreads();
-    if (i == 0) {
+    if (threadIdx.x == 0) {
         double np = 0, acc = 0;
         for (int c = 0; c < C; ++c) {
             const double pres = use_tmask ? (s[3 * C + c] > 0 ? 1.0 : 0.0) : 1.0;
@@ -160,7 +170,7 @@ extern "C" int lidog_dice_fwd(const float *logits, const int64_t *target, int64_
     k_dice_sums<C_><<<nb, 256, 0, st>>>(logits, target, n, ignore_label, has_ignore, t_on, t_off, powerize, ws)
     DICE_DISPATCH(CALL)
 #undef CALL
-    k_dice_finish<<<1, 64, 0, st>>>(ws, nb, C, use_tmask, offset, loss, coef);
+    k_dice_finish<<<1, 512, 0, st>>>(ws, nb, C, use_tmask, offset, loss, coef);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
