@@ -195,13 +195,17 @@ int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float
                    const float *w, const float *b, const float *residual, int32_t relu, float *y, void *stream);
 /* backward reduce: sums[0..2C) = (sum dy', sum dy'*xhat) with dy' = dy * (y > 0) when relu_y != NULL; ws as above;
  * count > 0: stored at sums[2*C]; db / dw != NULL: the LOCAL parameter gradients (float copies of the two sums) */
+/* relu_w / relu_b (both or neither; relu_y must then be NULL; [rows, C] with C % 4 == 0 only): the ReLU mask is
+ * recomputed from x with the forward pass's own expression ((x - mean) * invstd * w + b > 0, same bits) instead of
+ * being read from the saved output -- for a BatchNorm + ReLU WITHOUT residual, one tensor less to stream. */
 int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                         const float *mean, const float *invstd, double *sums, double *ws, double count, float *dw,
-                        float *db, void *stream);
-/* dx = w*invstd*(dy' - s0/count - xhat*s1/count); dres = dy' when dres != NULL; dw = s1, db = s0 when != NULL */
+                        float *db, const float *relu_w, const float *relu_b, void *stream);
+/* dx = w*invstd*(dy' - s0/count - xhat*s1/count); dres = dy' when dres != NULL; dw = s1, db = s0 when != NULL;
+ * relu_b: as above (w is the BatchNorm weight already) */
 int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                        const float *mean, const float *invstd, const float *w, const double *sums, double count,
-                       float *dx, float *dres, float *dw, float *db, void *stream);
+                       float *dx, float *dres, float *dw, float *db, const float *relu_b, void *stream);
 /* out[c] = sum over the n rows of x[., c] for a narrow matrix (C <= 16; the classifier's bias gradient); ws: 512*C
  * doubles */
 int lidog_colsum(const float *x, int64_t n, int32_t C, float *out, double *ws, void *stream);

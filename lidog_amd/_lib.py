@@ -44,8 +44,8 @@ SIGNATURES = {
     "lidog_bn_stats": [_p, _i64, _i32, _i64, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_bn_finalize": [_p, _d, _i32, _f, _f, _p, _p, _p, _p, _p],
     "lidog_bn_apply": [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
-    "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p],
-    "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
+    "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
+    "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p, _p],
     "lidog_colsum": [_p, _i64, _i32, _p, _p, _p],
     "lidog_colsum_ws": [_i32],
     "lidog_bn_eval_invstd": [_p, _f, _i32, _p, _p],

@@ -23,22 +23,32 @@ __device__ __forceinline__ void red_terms(float x, float dy, float ry, bool has_
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 
+// rw / rb (MODE 1, ry == NULL): BatchNorm weight and bias -- the ReLU mask is then recomputed from x with the forward
+// pass's own expression ((x - mean) * invstd * w + b > 0, same operation order, contraction off: the same bits)
+// instead of being read from the saved output: one tensor less to stream for a BatchNorm + ReLU without residual
 template <int MODE>
 __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict__ x, const float4 *__restrict__ dy,
                                                        const float4 *__restrict__ ry, int64_t n, int C4,
                                                        const float *__restrict__ mean,
                                                        const float *__restrict__ invstd,
-                                                       double *__restrict__ partial) {
+                                                       double *__restrict__ partial,
+                                                       const float *__restrict__ rw = nullptr,
+                                                       const float *__restrict__ rb = nullptr) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
     const int tid = threadIdx.x;
     const int r = tid / C4, c4 = tid % C4;
     const bool active = r < RB;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float m[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+    float m[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1}, gw[4] = {0, 0, 0, 0}, gb[4] = {1, 1, 1, 1};
+    const bool from_x = MODE == 1 && ry == nullptr && rw != nullptr;
     if (MODE == 1 && active) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { m[j] = mean[c4 * 4 + j]; is[j] = invstd[c4 * 4 + j]; }
+        if (from_x) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gw[j] = rw[c4 * 4 + j]; gb[j] = rb[c4 * 4 + j]; }
+        }
     }
     if (active) {
         const int64_t step = (int64_t)gridDim.x * RB;
@@ -65,10 +75,18 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
                 const float4 z = make_float4(0, 0, 0, 0);
                 float4 vv = (MODE == 0 && !ok) ? z : v[u];
                 float4 gg = ok ? g[u] : z;
-                red_terms<MODE>(vv.x, gg.x, y[u].x, ry != nullptr, m[0], is[0], a[0], a[4]);
-                red_terms<MODE>(vv.y, gg.y, y[u].y, ry != nullptr, m[1], is[1], a[1], a[5]);
-                red_terms<MODE>(vv.z, gg.z, y[u].z, ry != nullptr, m[2], is[2], a[2], a[6]);
-                red_terms<MODE>(vv.w, gg.w, y[u].w, ry != nullptr, m[3], is[3], a[3], a[7]);
+                float4 yy = y[u];
+                if (from_x) {   // the forward pass's pre-activation, bit for bit (k_bn_apply4)
+                    yy.x = (vv.x - m[0]) * is[0] * gw[0] + gb[0];
+                    yy.y = (vv.y - m[1]) * is[1] * gw[1] + gb[1];
+                    yy.z = (vv.z - m[2]) * is[2] * gw[2] + gb[2];
+                    yy.w = (vv.w - m[3]) * is[3] * gw[3] + gb[3];
+                }
+                const bool has_relu = ry != nullptr || from_x;
+                red_terms<MODE>(vv.x, gg.x, yy.x, has_relu, m[0], is[0], a[0], a[4]);
+                red_terms<MODE>(vv.y, gg.y, yy.y, has_relu, m[1], is[1], a[1], a[5]);
+                red_terms<MODE>(vv.z, gg.z, yy.z, has_relu, m[2], is[2], a[2], a[6]);
+                red_terms<MODE>(vv.w, gg.w, yy.w, has_relu, m[3], is[3], a[3], a[7]);
             }
         }
     }
@@ -225,7 +243,7 @@ static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4
 template <int MODE>
 static int launch_colreduce(const float *x, const float *dy, const float *ry, int64_t n, int C, int64_t hw,
                             const float *mean, const float *invstd, double *sums, double *ws, double count,
-                            BnFinish fin, hipStream_t st) {
+                            BnFinish fin, hipStream_t st, const float *rw = nullptr, const float *rb = nullptr) {
     if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     if (colreduce_uses_partials(C, hw)) {
         LIDOG_REQUIRE(ws != nullptr, "bn reduce: workspace of lidog_bn_reduce_ws() doubles required");
@@ -234,9 +252,10 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
         int64_t nb = cdiv64(n, (int64_t)RB * 16);
         if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
         k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
-                                                            n, C4, mean, invstd, ws);
+                                                            n, C4, mean, invstd, ws, rw, rb);
         lidog_launch_sums_finish(ws, (int)nb, C, sums, count, fin, st);
     } else {
+        LIDOG_REQUIRE(rw == nullptr, "bn reduce: the ReLU mask can be recomputed from x only for [rows, C] with C %% 4 == 0");
         // atomic variants accumulate: start from zero
         if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) return 1;
         if (hw == 1) {
@@ -272,9 +291,13 @@ extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, 
 
 extern "C" int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C,
                                    int64_t hw, const float *mean, const float *invstd, double *sums, double *ws,
-                                   double count, float *dw, float *db, void *stream) {
+                                   double count, float *dw, float *db, const float *relu_w, const float *relu_b,
+                                   void *stream) {
+    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) && !(relu_y && relu_w),
+                  "bn_bwd_reduce: pass either relu_y or (relu_w, relu_b)");
     BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
-    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, ws, count, fin, (hipStream_t)stream);
+    return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, ws, count, fin, (hipStream_t)stream,
+                               relu_w, relu_b);
 }
 
 __global__ void k_bn_finalize(const double *__restrict__ sums, double count, int C, float eps, float momentum,
@@ -438,19 +461,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float4 *__restrict_
                                                        const float *__restrict__ mean,
                                                        const float *__restrict__ invstd, const float *__restrict__ w,
                                                        const double *__restrict__ sums, double inv_count,
-                                                       float4 *__restrict__ dx, float4 *__restrict__ dres) {
+                                                       float4 *__restrict__ dx, float4 *__restrict__ dres,
+                                                       const float *__restrict__ rb) {
     const int C = C4 * 4;
     const int64_t stride = (int64_t)gridDim.x * 256;  // launcher makes this a multiple of C4
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const int c4 = (int)(i % C4);
     const double ic = (inv_count > 0) ? inv_count : 1.0 / sums[2 * C];
-    float mu[4], is[4], sc[4], m0[4], m1[4];
+    float mu[4], is[4], sc[4], m0[4], m1[4], gw[4], gb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int c = c4 * 4 + j;
         mu[j] = mean[c];
         is[j] = invstd[c];
+        gw[j] = w[c];
+        gb[j] = rb ? rb[c] : 0.f;
         sc[j] = is[j] * w[c];
         m0[j] = (float)(sums[c] * ic);
         m1[j] = (float)(sums[C + c] * ic);
@@ -461,6 +487,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float4 *__restrict_
             float4 y = ry[i];
             g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
             g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+        } else if (rb) {   // ReLU mask from the forward pass's pre-activation, recomputed bit for bit from x
+            g.x = ((xv.x - mu[0]) * is[0] * gw[0] + gb[0]) > 0.f ? g.x : 0.f;
+            g.y = ((xv.y - mu[1]) * is[1] * gw[1] + gb[1]) > 0.f ? g.y : 0.f;
+            g.z = ((xv.z - mu[2]) * is[2] * gw[2] + gb[2]) > 0.f ? g.z : 0.f;
+            g.w = ((xv.w - mu[3]) * is[3] * gw[3] + gb[3]) > 0.f ? g.w : 0.f;
         }
         float4 o;
         o.x = (g.x - m0[0] - (xv.x - mu[0]) * is[0] * m1[0]) * sc[0];
@@ -482,9 +513,11 @@ __global__ void k_bn_param_grads(const double *__restrict__ sums, int C, float *
 extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C,
                                   int64_t hw, const float *mean, const float *invstd, const float *w,
                                   const double *sums, double count, float *dx, float *dres, float *dw, float *db,
-                                  void *stream) {
+                                  const float *relu_b, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     int64_t total = n * C * hw;
+    LIDOG_REQUIRE(relu_b == nullptr || (relu_y == nullptr && hw == 1 && C % 4 == 0),
+                  "bn_bwd_apply: the ReLU mask can be recomputed from x only for [rows, C] with C %% 4 == 0");
     if (total > 0 && hw == 1 && C % 4 == 0) {
         int C4 = C / 4;
         int64_t total4 = total / 4;
@@ -498,7 +531,7 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
         k_bn_bwd_apply4<<<(unsigned)blocks, 256, 0, st>>>((const float4 *)dy, (const float4 *)x,
                                                           (const float4 *)relu_y, total4, C4, mean, invstd, w, sums,
                                                           count > 0 ? 1.0 / count : -1.0, (float4 *)dx,
-                                                          (float4 *)dres);
+                                                          (float4 *)dres, relu_b);
     } else if (total > 0 && hw >= 1024) {
         int chunks = (int)cdiv64(hw, 8192);
         if (chunks > 64) chunks = 64;

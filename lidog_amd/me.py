@@ -966,14 +966,19 @@ class _BatchNormFn(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         call("lidog_bn_apply", ptr(x), n, C, hw, ptr(mean), ptr(invstd), ptr(weight), ptr(bias), ptr(res),
              1 if relu else 0, ptr(y))
-        ctx.save_for_backward(x, weight, mean, invstd, y if relu else None)
+        # BatchNorm + ReLU without residual on a [rows, C] matrix: backward recomputes the ReLU mask from x (the forward
+        # pass's own expression, same bits) instead of reading y -- one tensor less in both backward kernels
+        mask_from_x = relu and residual is None and hw == 1 and C % 4 == 0
+        ctx.save_for_backward(x, weight, mean, invstd, y if (relu and not mask_from_x) else None,
+                              bias if mask_from_x else None)
         ctx.cfg = (n, C, hw, rows, training, residual is not None, group)
         ctx.params = (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, mean, invstd, y = ctx.saved_tensors
+        x, weight, mean, invstd, y, mask_b = ctx.saved_tensors
+        mask_w = weight if mask_b is not None else None
         n, C, hw, rows, training, has_res, group = ctx.cfg
         dy = dy.contiguous()
         dev = x.device
@@ -985,7 +990,7 @@ class _BatchNormFn(torch.autograd.Function):
         dw = dw if dw is not None else torch.empty(C, dtype=torch.float32, device=dev)
         db = db if db is not None else torch.empty(C, dtype=torch.float32, device=dev)
         call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums),
-             ptr(_bn_ws(C, hw, dev)), rows, ptr(dw), ptr(db))
+             ptr(_bn_ws(C, hw, dev)), rows, ptr(dw), ptr(db), ptr(mask_w), ptr(mask_b))
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         count = rows
@@ -996,7 +1001,7 @@ class _BatchNormFn(torch.autograd.Function):
             dist.all_reduce(sums, group=group)   # (sum dy', sum dy' xhat, rows)
             count = -1.0
         call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
-             ptr(sums), count, ptr(dx), ptr(dres), None, None)
+             ptr(sums), count, ptr(dx), ptr(dres), None, None, ptr(mask_b))
         return dx, dw, db, None, None, None, None, None, None, None, dres, None, None
 
 

@@ -22,8 +22,8 @@ for n, C, cnt in ((304000, 96, 5), (304000, 32, 1), (179000, 96, 5), (179000, 32
     by = 4.0 * n * C / 1e6  # MB per pass
     t_s = timeit(lambda: call("lidog_bn_stats", ptr(x), n, C, 1, ptr(sums), ptr(ws), float(n), 0.0, 0.0, None, None, None, None))
     t_a = timeit(lambda: call("lidog_bn_apply", ptr(x), n, C, 1, ptr(mean), ptr(inv), ptr(w), ptr(b), ptr(res), 1, ptr(out)))
-    t_r = timeit(lambda: call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, 1, ptr(mean), ptr(inv), ptr(sums), ptr(ws), float(n), None, None))
-    t_b = timeit(lambda: call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, 1, ptr(mean), ptr(inv), ptr(w), ptr(sums), float(n), ptr(out), ptr(dres), ptr(dw), ptr(db)))
+    t_r = timeit(lambda: call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, 1, ptr(mean), ptr(inv), ptr(sums), ptr(ws), float(n), None, None, None, None))
+    t_b = timeit(lambda: call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, 1, ptr(mean), ptr(inv), ptr(w), ptr(sums), float(n), ptr(out), ptr(dres), ptr(dw), ptr(db), None))
     print(f"n={n:7d} C={C:3d}: stats {1e3*t_s:6.1f} us {by/t_s/1e3:5.2f} TB/s | apply {1e3*t_a:6.1f} us {3*by/t_a/1e3:5.2f} TB/s | "
           f"bwd_reduce {1e3*t_r:6.1f} us {3*by/t_r/1e3:5.2f} TB/s | bwd_apply {1e3*t_b:6.1f} us {5*by/t_b/1e3:5.2f} TB/s")
     for i, t in enumerate((t_s, t_a, t_r, t_b)): tot[i] += t * cnt

@@ -165,6 +165,7 @@ def test_batchnorm_rows(C, relu, res):
     yg = ME.batch_norm(xg, mod.bn, 1, relu, rg if res else None)
     torch.testing.assert_close(yg.cpu(), y, rtol=1e-5, atol=2e-6)
     gy = torch.randn(y.shape, generator=g)
+    saved = yg.grad_fn.saved_tensors    # freed by backward()
     y.backward(gy)
     yg.backward(gy.cuda())
     torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-6)
@@ -174,6 +175,26 @@ def test_batchnorm_rows(C, relu, res):
         torch.testing.assert_close(rg.grad.cpu(), rr.grad, rtol=0, atol=0)
     torch.testing.assert_close(mod.bn.running_mean.cpu(), bn_ref.running_mean, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(mod.bn.running_var.cpu(), bn_ref.running_var, rtol=1e-5, atol=1e-6)
+    if relu and not res and C % 4 == 0:
+        # the backward pass above recomputed the ReLU mask from x; reading it from y instead must give the same bits
+        from lidog_amd._lib import call, ptr, load
+        xd, dyd = x.cuda(), gy.cuda()
+        _, w_s, mean_s, inv_s, y_saved, b_s = saved
+        assert y_saved is None and b_s is not None
+        yd = yg.detach()
+        outs = []
+        for use_y in (True, False):
+            sums = torch.empty(2 * C + 1, dtype=torch.float64, device="cuda")
+            ws = torch.empty(load().lidog_bn_reduce_ws(C, 1), dtype=torch.float64, device="cuda")
+            dwb = torch.empty(2, C, device="cuda")
+            call("lidog_bn_bwd_reduce", ptr(dyd), ptr(xd), ptr(yd) if use_y else None, n, C, 1, ptr(mean_s), ptr(inv_s),
+                 ptr(sums), ptr(ws), float(n), ptr(dwb[0]), ptr(dwb[1]), None if use_y else ptr(w_s), None if use_y else ptr(b_s))
+            dx = torch.empty_like(xd)
+            call("lidog_bn_bwd_apply", ptr(dyd), ptr(xd), ptr(yd) if use_y else None, n, C, 1, ptr(mean_s), ptr(inv_s),
+                 ptr(w_s), ptr(sums), float(n), ptr(dx), None, None, None, None if use_y else ptr(b_s))
+            outs.append((sums.clone(), dx, dwb))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+        assert torch.equal(outs[1][1], xg.grad)
     # eval mode uses the running statistics
     bn_ref.eval(), mod.eval()
     torch.testing.assert_close(ME.batch_norm(x.cuda(), mod.bn, 1, False, None).cpu(), bn_ref(x), rtol=1e-5, atol=2e-6)
