@@ -234,10 +234,11 @@ def main():
             run_eval(batches[i % 2]["coords_int"], batches[i % 2]["source_features0"], batches[(i + 1) % 2]["coords_int"])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(3, 11):
+        n_eval = 24
+        for i in range(3, 3 + n_eval):
             run_eval(batches[i % 2]["coords_int"], batches[i % 2]["source_features0"], batches[(i + 1) % 2]["coords_int"])
         torch.cuda.synchronize()
-        eval_rate = 8 * args.batch / (time.perf_counter() - t1)
+        eval_rate = n_eval * args.batch / (time.perf_counter() - t1)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

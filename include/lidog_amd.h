@@ -114,6 +114,11 @@ int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_ptr, const 
                                   int32_t C, const float *bias, float *out, double *sums, double *partial_ws,
                                   double count, float eps, float momentum, float *mean, float *invstd,
                                   float *running_mean, float *running_var, void *stream);
+/* Validation path (running statistics, minkunet_bev.py:376-393): the reduction with the evaluation-mode BatchNorm
+ * (+ residual + ReLU) in its epilogue, same expression and order as lidog_bn_apply. */
+int lidog_sconv_reduce_rows_bn(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n, int32_t C,
+                               const float *bias, const float *mean, const float *invstd, const float *w,
+                               const float *b, const float *residual, int32_t relu, float *out, void *stream);
 /* Reduction with the centre offset of a stride-1 odd kernel fused in (csrc/sconv_center.hip): out [n, Cout] = sum over
  * the per-row lists in ascending offset order, where the entry marked -1 is A[o] . Wc (Wc [Cin, Cout] = the centre
  * offset's weights), computed here on the matrix cores, and every other entry is a row of T (written by

@@ -29,6 +29,7 @@ SIGNATURES = {
     "lidog_sconv_center_reduce_ws": [_i64, _i32],
     "lidog_sconv_center_reduce": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p],
+    "lidog_sconv_reduce_rows_bn": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_sconv_reduce_rows_stats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
     "lidog_sconv_os_block_rows": [],

@@ -538,6 +538,54 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *
     }
 }
 
+// The same reduction with an evaluation-mode BatchNorm (+ residual + ReLU) applied in the epilogue: the validation path
+// (minkunet_bev.py:376-393, running statistics) needs no statistics pass, so the separate BatchNorm kernel and one
+// write + read of the convolution output go away.  Same expression and operation order as bn.hip:k_bn_apply4.
+__global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bn(const float4 *__restrict__ T,
+                                                               const int32_t *__restrict__ row_ptr,
+                                                               const int32_t *__restrict__ row_list, int64_t n, int C4,
+                                                               const float4 *__restrict__ bias,
+                                                               const float4 *__restrict__ mean,
+                                                               const float4 *__restrict__ invstd,
+                                                               const float4 *__restrict__ w,
+                                                               const float4 *__restrict__ b,
+                                                               const float4 *__restrict__ res, int relu,
+                                                               float4 *__restrict__ out) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * C4) return;
+    int64_t o = idx / C4;
+    int c4 = (int)(idx % C4);
+    float4 v = reduce_row_list(T, row_ptr, row_list, C4, o, c4);
+    if (bias) {
+        float4 bb = bias[c4];
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    const float4 m = mean[c4], s = invstd[c4], ww = w[c4], bb = b[c4];
+    v.x = (v.x - m.x) * s.x * ww.x + bb.x;
+    v.y = (v.y - m.y) * s.y * ww.y + bb.y;
+    v.z = (v.z - m.z) * s.z * ww.z + bb.z;
+    v.w = (v.w - m.w) * s.w * ww.w + bb.w;
+    if (res) { float4 r = res[idx]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    out[idx] = v;
+}
+
+extern "C" int lidog_sconv_reduce_rows_bn(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
+                                          int32_t C, const float *bias, const float *mean, const float *invstd,
+                                          const float *w, const float *b, const float *residual, int32_t relu,
+                                          float *out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    LIDOG_REQUIRE(C % 4 == 0 && C >= 4, "sconv_reduce_rows_bn: C must be a multiple of 4");
+    LIDOG_REQUIRE(mean && invstd && w && b, "sconv_reduce_rows_bn: BatchNorm vectors missing");
+    const int C4 = C / 4;
+    k_sconv_reduce_rows4_bn<<<(unsigned)cdiv64(n * C4, 256), 256, 0, st>>>(
+        (const float4 *)T, row_ptr, row_list, n, C4, (const float4 *)bias, (const float4 *)mean,
+        (const float4 *)invstd, (const float4 *)w, (const float4 *)b, (const float4 *)residual, relu, (float4 *)out);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lidog_sconv_reduce_rows(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
                                        int32_t C, const float *bias, const float *addend, float *out, void *stream) {
     hipStream_t st = (hipStream_t)stream;

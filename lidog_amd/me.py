@@ -328,7 +328,7 @@ class CoordinateManager:
             off += K + 1
             desc, n_tiles = _tiles_host(k_off_host)
             nc = None
-            if _center_of(key) >= 0:
+            if _center_of(key) >= 0 and _CENTER_FUSED:
                 desc_nc, n_nc = _tiles_host(k_off_host, _center_of(key))
                 nc = (arena.add(desc_nc), n_nc)
             todo.append(("kmap", key, pd, k_off_host, arena.add(desc), n_tiles, nc))
@@ -464,10 +464,13 @@ class CoordinateManager:
         # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient, the centre
         # entry marked; 2^3 stride 2: the strided convolution's forward and the transposed convolution's data
         # gradient, both over the coarse rows)
-        if m.center >= 0 and K == 27:
-            self._own(*m.rows("out", True), *m.rows("in", True))
-            if m._tiles_nc is None:
-                self._own(m.tiles_nc[0])
+        if K == 27:
+            mark = m.center >= 0 and _CENTER_FUSED     # the lists the reduction passes will ask for
+            self._own(*m.rows("out", False), *m.rows("in", False))
+            if mark:
+                self._own(*m.rows("out", True), *m.rows("in", True))
+                if m._tiles_nc is None:
+                    self._own(m.tiles_nc[0])
         elif K == 8:
             self._own(*m.rows("out"))
         return m
@@ -1078,9 +1081,9 @@ class _ConvBase(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
 
-    def forward(self, x, stats=None, skip=False):
-        """`skip=True` returns (conv(x), x'): x' is x again, but routed through this convolution's autograd node
-        so that the gradient of a residual branch taken from x' is added inside the data gradient's reduction"""
+    def _resolve(self, x):
+        """(kernel map, output map key, swap, single_out, single_in) of this convolution on x's coordinate map; records
+        the use in the manager's trace (CoordinateManager.prepare builds the next batch's maps from it)"""
         cm, s_in = x.coordinate_manager, x.coordinate_map_key
         if self.kernel_volume == 1 and self.stride == 1:
             m, s_out, swap, single_out, single_in = cm.identity_map(x.F.shape[0]), s_in, False, True, True
@@ -1099,10 +1102,41 @@ class _ConvBase(nn.Module):
             cm.trace.append(((s_out, s_in, self.kernel_size, self.dilation), self.in_channels, self.out_channels))
             swap, single_in = True, False
             single_out = self.stride == self.kernel_size and self.stride > 1
+        return m, s_out, swap, single_out, single_in
+
+    def forward(self, x, stats=None, skip=False):
+        """`skip=True` returns (conv(x), x'): x' is x again, but routed through this convolution's autograd node
+        so that the gradient of a residual branch taken from x' is added inside the data gradient's reduction"""
+        cm, s_in = x.coordinate_manager, x.coordinate_map_key
+        m, s_out, swap, single_out, single_in = self._resolve(x)
         out = _SparseConvFn.apply(x.F, self.kernel, self.bias, m, swap, single_out, single_in, stats, skip)
         if skip:
             return (SparseTensor(out[0], coordinate_manager=cm, coordinate_map_key=s_out),
                     SparseTensor(out[1], coordinate_manager=cm, coordinate_map_key=s_in))
+        return SparseTensor(out, coordinate_manager=cm, coordinate_map_key=s_out)
+
+    def forward_eval_bn(self, x, bn, relu, residual):
+        """Validation path, no autograd: convolution whose reduction pass applies the evaluation-mode BatchNorm
+        (+ residual + ReLU) in its epilogue (lidog_sconv_reduce_rows_bn) -- no separate BatchNorm kernel, no round
+        trip of the convolution output.  Returns None when this convolution does not go through the reduction
+        pass (1x1, transposed k2 s2, the 5^3 stem, channel counts not a multiple of 4): the caller falls back."""
+        if self.kernel_volume == 1 or self.transposed or self.in_channels == 1 or self.out_channels % 4:
+            return None
+        cm = x.coordinate_manager
+        m, s_out, swap, single_out, single_in = self._resolve(x)
+        xf = x.F.contiguous()
+        W3 = self.kernel.detach().contiguous().view(m.K, self.in_channels, self.out_channels)
+        Cin, Cout, dev = self.in_channels, self.out_channels, xf.device
+        T = torch.empty((m.P, Cout), dtype=torch.float32, device=dev)
+        _gemm(xf, m.pair_in, W3, None, m, Cin, Cout, T, None)
+        row_ptr, row_list = m.rows("out")
+        invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+        call("lidog_bn_eval_invstd", ptr(bn.running_var), float(bn.eps), Cout, ptr(invstd))
+        out = torch.empty((m.n_out, Cout), dtype=torch.float32, device=dev)
+        res = residual.F.contiguous() if residual is not None else None
+        call("lidog_sconv_reduce_rows_bn", ptr(T), ptr(row_ptr), ptr(row_list), m.n_out, Cout,
+             ptr(self.bias.detach()) if self.bias is not None else None, ptr(bn.running_mean), ptr(invstd),
+             ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(res), 1 if relu else 0, ptr(out))
         return SparseTensor(out, coordinate_manager=cm, coordinate_map_key=s_out)
 
 
@@ -1181,6 +1215,11 @@ def conv_bn(conv, bn_module, x, relu=False, residual=None, skip=False):
     req = None
     if bn.training or not bn.track_running_stats:
         req = StatsRequest(bn, bn_module._sync_group() is not None, _training_momentum(bn))
+    elif not skip and not torch.is_grad_enabled() and bn.affine:
+        # validation path under no_grad: BatchNorm applied in the reduction pass's epilogue where there is one
+        y = conv.forward_eval_bn(x, bn, relu, residual)
+        if y is not None:
+            return y
     if skip:
         y, x_alias = conv(x, stats=req, skip=True)
         return bn_module(y, relu=relu, residual=residual, stats=req), x_alias
