@@ -341,6 +341,61 @@ int lidog_comm_destroy(void *comm);
 int lidog_allreduce_f32(float *buf, int64_t n, void *comm, void *stream);
 int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *stream);
 
+/* ------------------------------------------------------------------ host-side tables of a kernel map (csrc/hostprep.hip)
+ * Pure host code.  k_off_host [K+1]: the rule book's offsets (lidog_kernel_map_pairs' k_off copied to the host).
+ * lidog_tiles_host: the (tile_k, tile_row0, tile_rows) descriptors lidog_sconv_gemm takes, `tile_rows` (128) pairs per
+ * tile, never straddling an offset, in launch order; skip_k >= 0 leaves that offset out.  Written as a contiguous
+ * [3][n_tiles] int32 array at `out` (capacity `cap` tiles); returns n_tiles or -1.
+ * lidog_wgrad_items_host: the work items lidog_sconv_wgrad takes ([4][n]: k, first pair, end pair, launch order;
+ * item_off [K+1]); order_mode 0 = by offset, 1 = same relative position together, 2 = 1 in XCD-sized groups of
+ * `group`.  Returns n or -1. */
+int64_t lidog_tiles_host(const int64_t *k_off_host, int32_t K, int32_t skip_k, int32_t tile_rows, int32_t *out,
+                         int64_t cap);
+int64_t lidog_wgrad_items_host(const int64_t *k_off_host, int32_t K, int64_t chunk, int32_t order_mode, int32_t group,
+                               int32_t *items, int32_t *item_off, int64_t cap);
+
+/* ------------------------------------------------------------------ trunk executor (csrc/trunk.hip)
+ * The whole MinkUNet encoder-decoder -- stem, 4 x (strided convolution + BasicBlocks), 4 x (transposed convolution +
+ * ME.cat + BasicBlocks), classifier: utils/models/minkunet_bev.py:302-374, utils/models/minkunet.py:97-158 -- forward
+ * and backward in ONE call each.  The reference's forward is ~190 python-level ME calls per pass; the operator path of
+ * this library (one entry point per operator) costs ~12 ms of host dispatch per training step.  Here the launch
+ * sequence comes from tables: the same entry points above are called in the same order with the same arguments, so
+ * results are bit-identical to calling them one by one.
+ *
+ * Tables (int64 rows, host memory; pointers are device pointers stored as integers):
+ *   convs [n_convs][20]: kind (0 = 3^3 stride 1, 1 = 2^3 stride 2, 2 = transposed 2^3 stride 2, 3 = 1x1, 4 = C_in 1
+ *         stem through the neighbour table), map row, C_in, C_out, K, W [K,C_in,C_out], Wt [K,C_out,C_in] or 0
+ *         (transposed here), gW, bias or 0, g_bias or 0, BatchNorm weight, bias, running_mean, running_var, g_weight,
+ *         g_bias (0 for a convolution without BatchNorm), weight-gradient work items, their count, item_off
+ *         (lidog_sconv_wgrad), 0;   conv_f [n_convs][2]: BatchNorm eps, momentum
+ *   maps  [n_maps][16]: K, n_in, n_out, pairs, pair_in, pair_out, row_ptr / row_list of the output rows, of the input
+ *         rows (lidog_kernel_map_rows; 0 where unused), tile descriptors [3][n_tiles], n_tiles, neighbour table
+ *         (stem) or 0, identity rows 0..n-1 (1x1) or 0
+ *   ops   [n_ops][8]: type (0 = convolution + BatchNorm, 1 = concatenation, 2 = convolution), convolution row, input
+ *         buffer, output buffer, ReLU, residual buffer or -1, fold (the gradient already accumulated for the input
+ *         buffer -- the residual branch of a BasicBlock -- enters the data gradient's reduction as its addend), second
+ *         input of a concatenation
+ *   bufs  [n_bufs][4]: level (index into level_rows), channels, external slot or -1 (lives in the arena)
+ *   ext / ext_grad [slots]: the caller's tensors: slot 0 = input features (no gradient), the others outputs; incoming
+ *         gradients (0 = none)
+ * Memory: see the notes on arena / garena / scratch / lane_scratch in csrc/trunk.hip.  dry != 0: nothing is launched,
+ * need[] receives the bytes of each region for this batch.  rec [n_ops * 4 + n_bufs]: written by forward, read by
+ * backward (arena offsets).  Training-mode BatchNorm with local statistics only (SyncBatchNorm: operator path). */
+int lidog_trunk_forward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
+                        int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs,
+                        const int64_t *level_rows, const int64_t *ext, void *arena, int64_t arena_bytes,
+                        void *scratch, int64_t scratch_bytes, int64_t *rec, int64_t *need /*[2]*/, int32_t dry,
+                        void *stream);
+/* lane: second stream for the weight gradients (NULL = in line), forked behind each data gradient's GEMM
+ * (wgrad_first = 0) or before it; joined into `stream` before the call returns. */
+int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
+                         int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs,
+                         const int64_t *level_rows, const int64_t *ext, const int64_t *ext_grad, void *arena,
+                         const int64_t *rec, void *garena, int64_t garena_bytes, void *scratch,
+                         int64_t scratch_bytes, void *lane_scratch, int64_t lane_bytes, int64_t *need /*[3]*/,
+                         int32_t *conv_done_host /*[n_convs]: 1 = this convolution's parameter gradients were written*/,
+                         int32_t dry, int32_t wgrad_first, void *stream, void *lane);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@ Public surface:
   lidog_amd.MinkUNet34 / MinkUNet34BEV    the reference models wired to those operators
   lidog_amd.losses        SoftDICELoss / DICELoss on the device
   lidog_amd.trainer       training step, Adam, RCCL data parallelism
+  lidog_amd.trunk         the whole encoder-decoder as one launch sequence per pass (csrc/trunk.hip)
 """
 import os as _os
 
@@ -13,8 +14,10 @@ import os as _os
 # is 4 queues for all streams of a process); only effective when set before the HIP runtime starts
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from . import me, bev, losses  # noqa: E402,F401
+from . import me, bev, losses, trunk  # noqa: E402,F401
 from .minkunet import make_models  # noqa: E402
+
+me.trunk_forward = trunk.trunk_forward   # the models hand their training-mode trunk pass to the executor
 
 _models = make_models(me, bev.Encoder2D, bev.sparse2super)
 MinkUNet34 = _models.MinkUNet34

@@ -81,9 +81,15 @@ SIGNATURES = {
     "lidog_comm_destroy": [_p],
     "lidog_allreduce_f32": [_p, _i64, _p, _p],
     "lidog_allreduce_f64": [_p, _i64, _p, _p],
+    "lidog_tiles_host": [_p, _i32, _i32, _i32, _p, _i64],
+    "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
+    "lidog_trunk_forward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p],
+    "lidog_trunk_backward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
+                             _i64, _p, _p, _i32, _i32, _p, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
-             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_sconv_center_reduce_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64}
+             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_sconv_center_reduce_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
+             "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64}
 
 _lib = None
 

@@ -1,0 +1,468 @@
+// Trunk executor: the MinkUNet encoder-decoder (utils/models/minkunet_bev.py:302-399, utils/models/minkunet.py:97-158)
+// forward and backward as ONE host call each.
+//
+// The python operator path (lidog_amd/me.py) issues ~1 000 launches per training step through ~550 autograd nodes; the
+// launch sequence itself is static (63 convolutions, 62 BatchNorms, 4 concatenations) -- only row counts and map
+// pointers change per batch.  This file walks a table-driven program and calls the SAME entry points of this library
+// in the same order with the same arguments as me._SparseConvFn / me._BatchNormFn / me._Cat2Fn do, so every result is
+// bit-identical to the operator path (tests/test_gpu_trunk.py); what changes is the host cost of a step.
+//
+// No state is kept between calls except a pool of timing-less events for the second backward stream.  All memory comes
+// from the caller: `arena` (activations that live until backward), `garena` (gradients; never reused inside one
+// backward pass, so the weight gradients running on the lane stream may read them at any time), `scratch` (product
+// rows, reduction workspaces: main stream only), `lane_scratch` (weight-gradient partial slabs: lane stream only).
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+// ---- table layouts (int64 rows; python fills them as numpy arrays, lidog_amd/trunk.py)
+enum { TC_KIND, TC_MAP, TC_CIN, TC_COUT, TC_K, TC_W, TC_WT, TC_GW, TC_BIAS, TC_GBIAS, TC_BNW, TC_BNB, TC_BNRM, TC_BNRV,
+       TC_GBNW, TC_GBNB, TC_ITEMS, TC_NITEMS, TC_ITEMOFF, TC_COLS = 20 };
+enum { TM_K, TM_NIN, TM_NOUT, TM_P, TM_PAIR_IN, TM_PAIR_OUT, TM_RP_OUT, TM_RL_OUT, TM_RP_IN, TM_RL_IN, TM_TILES,
+       TM_NTILES, TM_NBR, TM_IDENT, TM_COLS = 16 };
+enum { TO_TYPE, TO_CONV, TO_IN, TO_OUT, TO_RELU, TO_RES, TO_FOLD, TO_B, TO_COLS = 8 };
+enum { TB_LEVEL, TB_CH, TB_EXT, TB_COLS = 4 };
+enum { REC_PRE, REC_MEAN, REC_INVSTD, REC_COLS = 4 };
+
+enum { KIND_K3 = 0, KIND_DOWN = 1, KIND_UP = 2, KIND_1X1 = 3, KIND_STEM = 4 };
+enum { OP_CONVBN = 0, OP_CAT = 1, OP_CONV = 2 };
+
+struct Bump {
+    char *base;
+    int64_t off, cap, peak;
+    bool dry;
+    void reset() { off = 0; }
+    void *take(int64_t bytes) {
+        int64_t a = (bytes + 255) / 256 * 256;
+        void *p = dry ? (void *)(uintptr_t)(4096 + off) : (void *)(base + off);
+        off += a;
+        if (off > peak) peak = off;
+        return p;
+    }
+    bool ok() const { return dry || peak <= cap; }
+};
+
+struct Ctx {
+    const int64_t *convs;
+    const double *conv_f;
+    int n_convs;
+    const int64_t *maps;
+    int n_maps;
+    const int64_t *ops;
+    int n_ops;
+    const int64_t *bufs;
+    int n_bufs;
+    const int64_t *level_rows;
+    const int64_t *ext;
+    bool dry;
+    int64_t rows(int b) const { return level_rows[bufs[b * TB_COLS + TB_LEVEL]]; }
+    int ch(int b) const { return (int)bufs[b * TB_COLS + TB_CH]; }
+    int64_t bytes(int b) const { return rows(b) * ch(b) * 4; }
+};
+
+template <typename T>
+inline T *P(int64_t v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v)); }
+
+#define TRY(expr)                 \
+    do {                          \
+        if (!ctx.dry) {           \
+            int _rc = (expr);     \
+            if (_rc) return _rc;  \
+        }                         \
+    } while (0)
+
+// events for forking the lane stream behind the main stream (one per convolution) and joining it again
+hipEvent_t *event_pool(int n) {
+    static std::vector<hipEvent_t> pool;
+    while ((int)pool.size() < n) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        pool.push_back(e);
+    }
+    return pool.data();
+}
+
+int check_tables(const Ctx &ctx, bool grads) {
+    LIDOG_REQUIRE(ctx.n_convs > 0 && ctx.n_ops > 0 && ctx.n_bufs > 0 && ctx.n_maps > 0, "trunk: empty tables");
+    for (int b = 0; b < ctx.n_bufs; ++b)
+        LIDOG_REQUIRE(ctx.rows(b) > 0 && ctx.ch(b) > 0, "trunk: buffer %d has no rows or channels", b);
+    for (int o = 0; o < ctx.n_ops; ++o) {
+        const int64_t *op = ctx.ops + (int64_t)o * TO_COLS;
+        auto buf_ok = [&](int64_t b) { return b >= 0 && b < ctx.n_bufs; };
+        LIDOG_REQUIRE(buf_ok(op[TO_IN]) && buf_ok(op[TO_OUT]), "trunk: op %d names a missing buffer", o);
+        if (op[TO_TYPE] == OP_CAT) {
+            LIDOG_REQUIRE(buf_ok(op[TO_B]), "trunk: op %d names a missing buffer", o);
+            int a = (int)op[TO_IN], b = (int)op[TO_B], out = (int)op[TO_OUT];
+            LIDOG_REQUIRE(ctx.rows(a) == ctx.rows(b) && ctx.rows(a) == ctx.rows(out) &&
+                              ctx.ch(a) + ctx.ch(b) == ctx.ch(out) && ctx.ch(a) % 4 == 0 && ctx.ch(b) % 4 == 0,
+                          "trunk: op %d concatenates mismatching buffers", o);
+            continue;
+        }
+        LIDOG_REQUIRE(op[TO_CONV] >= 0 && op[TO_CONV] < ctx.n_convs, "trunk: op %d names a missing convolution", o);
+        const int64_t *c = ctx.convs + op[TO_CONV] * TC_COLS;
+        LIDOG_REQUIRE(c[TC_MAP] >= 0 && c[TC_MAP] < ctx.n_maps, "trunk: op %d names a missing map", o);
+        const int64_t *m = ctx.maps + c[TC_MAP] * TM_COLS;
+        const int kind = (int)c[TC_KIND];
+        const int64_t n_in = kind == KIND_UP ? m[TM_NOUT] : m[TM_NIN], n_out = kind == KIND_UP ? m[TM_NIN] : m[TM_NOUT];
+        LIDOG_REQUIRE(ctx.rows((int)op[TO_IN]) == n_in && ctx.rows((int)op[TO_OUT]) == n_out,
+                      "trunk: op %d: buffers of %lld -> %lld rows on a map of %lld -> %lld rows", o,
+                      (long long)ctx.rows((int)op[TO_IN]), (long long)ctx.rows((int)op[TO_OUT]), (long long)n_in,
+                      (long long)n_out);
+        LIDOG_REQUIRE(ctx.ch((int)op[TO_IN]) == c[TC_CIN] && ctx.ch((int)op[TO_OUT]) == c[TC_COUT],
+                      "trunk: op %d: channel counts do not match its convolution", o);
+        LIDOG_REQUIRE(m[TM_K] == c[TC_K] && m[TM_NTILES] > 0 && m[TM_TILES], "trunk: op %d: map / kernel mismatch", o);
+        LIDOG_REQUIRE(c[TC_W] && (c[TC_GW] || !grads), "trunk: op %d: missing weights", o);
+        if (op[TO_TYPE] == OP_CONVBN) {
+            LIDOG_REQUIRE(c[TC_COUT] % 4 == 0, "trunk: op %d: BatchNorm width must be a multiple of 4", o);
+            LIDOG_REQUIRE(c[TC_BNW] && c[TC_BNB] && c[TC_BNRM] && c[TC_BNRV] && ((c[TC_GBNW] && c[TC_GBNB]) || !grads),
+                          "trunk: op %d: missing BatchNorm tensors", o);
+            if (op[TO_RES] >= 0)
+                LIDOG_REQUIRE(buf_ok(op[TO_RES]) && ctx.bytes((int)op[TO_RES]) == ctx.bytes((int)op[TO_OUT]),
+                              "trunk: op %d: residual of another shape", o);
+        }
+        switch (kind) {
+            case KIND_K3:
+                LIDOG_REQUIRE(m[TM_PAIR_IN] && m[TM_PAIR_OUT] && m[TM_RP_OUT] && m[TM_RL_OUT] && m[TM_RP_IN] &&
+                                  m[TM_RL_IN] && c[TC_CIN] % 4 == 0,
+                              "trunk: op %d: 3^3 map without pair or row lists", o);
+                break;
+            case KIND_DOWN:
+            case KIND_UP:
+                LIDOG_REQUIRE(m[TM_PAIR_IN] && m[TM_PAIR_OUT] && m[TM_RP_OUT] && m[TM_RL_OUT] && c[TC_CIN] % 4 == 0,
+                              "trunk: op %d: 2^3 map without pair or row lists", o);
+                break;
+            case KIND_1X1:
+                LIDOG_REQUIRE(m[TM_IDENT] && m[TM_K] == 1, "trunk: op %d: 1x1 convolution without identity rows", o);
+                break;
+            case KIND_STEM:
+                LIDOG_REQUIRE(m[TM_NBR] && m[TM_PAIR_IN] && m[TM_PAIR_OUT] && c[TC_CIN] == 1,
+                              "trunk: op %d: stem without neighbour table", o);
+                break;
+            default:
+                LIDOG_REQUIRE(false, "trunk: op %d: unknown convolution kind %d", o, kind);
+        }
+    }
+    return 0;
+}
+
+inline const int32_t *tile_row(const int64_t *m, int r) { return P<const int32_t>(m[TM_TILES]) + r * m[TM_NTILES]; }
+
+int gemm(const Ctx &ctx, const int64_t *m, const float *A, const int32_t *gather, const float *B, const float *bias,
+         int Cin, int Cout, float *out, const int32_t *scatter, void *st) {
+    TRY(lidog_sconv_gemm(A, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2), (int32_t)m[TM_NTILES], Cin,
+                         Cout, out, scatter, st));
+    return 0;
+}
+
+}  // namespace
+
+// Forward pass.  rec [n_ops * 4 + n_bufs]: arena offsets of what backward needs (filled here, opaque to the caller).
+// need [2]: bytes of arena / scratch this batch takes (always filled; with dry != 0 nothing is launched).
+extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
+                                   int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs,
+                                   int32_t n_bufs, const int64_t *level_rows, const int64_t *ext, void *arena,
+                                   int64_t arena_bytes, void *scratch, int64_t scratch_bytes, int64_t *rec,
+                                   int64_t *need, int32_t dry, void *stream) {
+    Ctx ctx{convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows, ext, dry != 0};
+    if (int rc = check_tables(ctx, false)) return rc;
+    if (!ctx.dry) {
+        // sizes first: nothing is launched into an arena that is too small
+        int64_t want[2];
+        if (int rc = lidog_trunk_forward(convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows,
+                                         ext, nullptr, 0, nullptr, 0, rec, want, 1, stream))
+            return rc;
+        LIDOG_REQUIRE(arena && scratch && want[0] <= arena_bytes && want[1] <= scratch_bytes,
+                      "trunk: forward needs %lld B of arena and %lld B of scratch, got %lld / %lld", (long long)want[0],
+                      (long long)want[1], (long long)arena_bytes, (long long)scratch_bytes);
+    }
+    Bump ar{(char *)arena, 0, arena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry};
+    int64_t *buf_off = rec + (int64_t)n_ops * REC_COLS;
+    // activation buffers: external ones are the caller's tensors, the others live in the arena
+    std::vector<float *> bp(n_bufs, nullptr);
+    for (int b = 0; b < n_bufs; ++b) {
+        int64_t e = bufs[b * TB_COLS + TB_EXT];
+        if (e >= 0) {
+            bp[b] = P<float>(ext[e]);
+            buf_off[b] = -1;
+            LIDOG_REQUIRE(ctx.dry || bp[b], "trunk: external buffer %d missing", b);
+        } else {
+            buf_off[b] = ar.off;
+            bp[b] = (float *)ar.take(ctx.bytes(b));
+        }
+    }
+    for (int o = 0; o < n_ops; ++o) {
+        const int64_t *op = ops + (int64_t)o * TO_COLS;
+        int64_t *r = rec + (int64_t)o * REC_COLS;
+        sc.reset();
+        if (op[TO_TYPE] == OP_CAT) {
+            int a = (int)op[TO_IN], b = (int)op[TO_B];
+            TRY(lidog_cat2(bp[a], ctx.ch(a), bp[b], ctx.ch(b), ctx.rows(a), bp[op[TO_OUT]], stream));
+            continue;
+        }
+        const int64_t *c = convs + op[TO_CONV] * TC_COLS;
+        const int64_t *m = maps + c[TC_MAP] * TM_COLS;
+        const int kind = (int)c[TC_KIND], Cin = (int)c[TC_CIN], Cout = (int)c[TC_COUT], K = (int)c[TC_K];
+        const bool bn = op[TO_TYPE] == OP_CONVBN;
+        const float *x = bp[op[TO_IN]];
+        const int64_t n = ctx.rows((int)op[TO_OUT]);
+        const float *W = P<const float>(c[TC_W]), *bias = P<const float>(c[TC_BIAS]);
+        float *y = bp[op[TO_OUT]];
+        float *pre = y, *mean = nullptr, *invstd = nullptr;
+        const float eps = (float)conv_f[op[TO_CONV] * 2], mom = (float)conv_f[op[TO_CONV] * 2 + 1];
+        if (bn) {
+            r[REC_PRE] = ar.off;
+            pre = (float *)ar.take(n * Cout * 4);
+            r[REC_MEAN] = ar.off;
+            mean = (float *)ar.take(Cout * 4);
+            r[REC_INVSTD] = ar.off;
+            invstd = (float *)ar.take(Cout * 4);
+        }
+        float *rm = P<float>(c[TC_BNRM]), *rv = P<float>(c[TC_BNRV]);
+        bool stats_done = false;
+        if (kind == KIND_K3 || kind == KIND_DOWN) {
+            // gathered GEMM into product rows, per-row reduction (+ BatchNorm statistics in its epilogue)
+            float *T = (float *)sc.take(m[TM_P] * Cout * 4);
+            if (int rc = gemm(ctx, m, x, P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T, nullptr, stream))
+                return rc;
+            const int32_t *rp = P<const int32_t>(m[TM_RP_OUT]), *rl = P<const int32_t>(m[TM_RL_OUT]);
+            if (bn) {
+                double *sums = (double *)sc.take((2 * Cout + 1) * 8);
+                double *ws = (double *)sc.take(lidog_sconv_reduce_stats_ws(n, Cout) * 8);
+                TRY(lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, eps, mom, mean,
+                                                  invstd, rm, rv, stream));
+                stats_done = true;
+            } else {
+                TRY(lidog_sconv_reduce_rows(T, rp, rl, n, Cout, bias, nullptr, pre, stream));
+            }
+        } else if (kind == KIND_UP) {
+            // transposed 2^3 stride 2: every fine row has exactly one pair, the GEMM scatters straight into the output
+            if (int rc = gemm(ctx, m, x, P<const int32_t>(m[TM_PAIR_OUT]), W, bias, Cin, Cout, pre,
+                              P<const int32_t>(m[TM_PAIR_IN]), stream))
+                return rc;
+        } else if (kind == KIND_1X1) {
+            if (int rc = gemm(ctx, m, x, nullptr, W, bias, Cin, Cout, pre, nullptr, stream)) return rc;
+        } else {
+            TRY(lidog_sconv_cin1(x, P<const int32_t>(m[TM_NBR]), W, bias, n, K, Cout, pre, stream));
+        }
+        if (!bn) continue;
+        if (!stats_done) {
+            double *sums = (double *)sc.take((2 * Cout + 1) * 8);
+            int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
+            double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
+            TRY(lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, eps, mom, mean, invstd, rm, rv, stream));
+        }
+        const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
+        TRY(lidog_bn_apply(pre, n, Cout, 1, mean, invstd, P<const float>(c[TC_BNW]), P<const float>(c[TC_BNB]), res,
+                           (int32_t)op[TO_RELU], y, stream));
+    }
+    need[0] = ar.peak;
+    need[1] = sc.peak;
+    return 0;
+}
+
+// Backward pass.  ext_grad [n_ext]: incoming gradients of the external buffers (0 = none; read only).  Parameter
+// gradients are written to the gW / g_bias / g_bn_* pointers of the convolution table.  lane: second stream for the
+// weight gradients (NULL = in line); wgrad_first: queue a weight gradient before its data gradient's GEMM instead of
+// behind it (me._WgradLane modes 1 / 2).  On return the main stream has been made to wait for the lane.
+// need [3]: bytes of garena / scratch / lane_scratch.  conv_done [n_convs] (host): 1 for every convolution whose
+// parameter gradients were written (a gradient reached its output), else 0.
+extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
+                                    int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs,
+                                    int32_t n_bufs, const int64_t *level_rows, const int64_t *ext,
+                                    const int64_t *ext_grad, void *arena, const int64_t *rec, void *garena,
+                                    int64_t garena_bytes, void *scratch, int64_t scratch_bytes, void *lane_scratch,
+                                    int64_t lane_bytes, int64_t *need, int32_t *conv_done, int32_t dry,
+                                    int32_t wgrad_first, void *stream, void *lane) {
+    Ctx ctx{convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows, ext, dry != 0};
+    if (int rc = check_tables(ctx, true)) return rc;
+    if (!ctx.dry) {
+        int64_t want[3];
+        if (int rc = lidog_trunk_backward(convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows,
+                                          ext, ext_grad, arena, rec, nullptr, 0, nullptr, 0, nullptr, 0, want,
+                                          conv_done, 1, wgrad_first, stream, lane))
+            return rc;
+        LIDOG_REQUIRE(arena && garena && scratch && (lane_scratch || !lane) && want[0] <= garena_bytes &&
+                          want[1] <= scratch_bytes && want[2] <= lane_bytes,
+                      "trunk: backward needs %lld / %lld / %lld B (gradients / scratch / lane), got %lld / %lld / %lld",
+                      (long long)want[0], (long long)want[1], (long long)want[2], (long long)garena_bytes,
+                      (long long)scratch_bytes, (long long)lane_bytes);
+    }
+    Bump ga{(char *)garena, 0, garena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry},
+        ls{(char *)lane_scratch, 0, lane_bytes, 0, ctx.dry};
+    hipStream_t main_st = (hipStream_t)stream, lane_st = (hipStream_t)lane;
+    hipEvent_t *events = nullptr;
+    if (lane && !ctx.dry) {
+        events = event_pool(n_convs + 1);
+        LIDOG_REQUIRE(events, "trunk: cannot create events");
+    }
+    const int64_t *buf_off = rec + (int64_t)n_ops * REC_COLS;
+    std::vector<float *> bp(n_bufs, nullptr);
+    // gradient slot of every buffer: 0 = nothing yet, 1 = the caller's tensor (read only), 2 = ours (garena)
+    std::vector<float *> gp(n_bufs, nullptr);
+    std::vector<int> gs(n_bufs, 0);
+    for (int b = 0; b < n_bufs; ++b) {
+        int64_t e = bufs[b * TB_COLS + TB_EXT];
+        if (e >= 0) {
+            bp[b] = P<float>(ext[e]);
+            if (ext_grad[e]) {
+                gp[b] = P<float>(ext_grad[e]);
+                gs[b] = 1;
+            }
+        } else {
+            bp[b] = ctx.dry ? (float *)(uintptr_t)4096 : (float *)((char *)arena + buf_off[b]);
+        }
+    }
+    // where a producer writes its contribution to buffer b's gradient, and what happens once it is queued
+    auto target = [&](int b) { return (float *)ga.take(ctx.bytes(b)); };
+    auto commit = [&](int b, float *p) -> int {
+        if (gs[b] == 0) {
+            gp[b] = p;
+            gs[b] = 2;
+            return 0;
+        }
+        float *dst = gs[b] == 2 ? gp[b] : (float *)ga.take(ctx.bytes(b));
+        TRY(lidog_add(gp[b], p, ctx.rows(b) * ctx.ch(b), dst, stream));
+        gp[b] = dst;
+        gs[b] = 2;
+        return 0;
+    };
+    int lane_used = 0;
+    for (int i = 0; i < n_convs; ++i) conv_done[i] = 0;
+    for (int o = n_ops - 1; o >= 0; --o) {
+        const int64_t *op = ops + (int64_t)o * TO_COLS;
+        const int64_t *r = rec + (int64_t)o * REC_COLS;
+        sc.reset();
+        const int out_b = (int)op[TO_OUT], in_b = (int)op[TO_IN];
+        if (gs[out_b] == 0) continue;  // nothing reached this output: no gradients below it on this branch
+        if (op[TO_TYPE] == OP_CAT) {
+            int a = in_b, b = (int)op[TO_B];
+            float *ga_ = target(a), *gb_ = target(b);
+            TRY(lidog_split2(gp[out_b], ctx.ch(a), ctx.ch(b), ctx.rows(a), ga_, gb_, stream));
+            if (int rc = commit(a, ga_)) return rc;
+            if (int rc = commit(b, gb_)) return rc;
+            continue;
+        }
+        const int64_t *c = convs + op[TO_CONV] * TC_COLS;
+        const int64_t *m = maps + c[TC_MAP] * TM_COLS;
+        const int kind = (int)c[TC_KIND], Cin = (int)c[TC_CIN], Cout = (int)c[TC_COUT], K = (int)c[TC_K];
+        const int64_t n = ctx.rows(out_b), n_in = ctx.rows(in_b);
+        conv_done[op[TO_CONV]] = 1;
+        const float *gout = gp[out_b];
+        if (op[TO_TYPE] == OP_CONVBN) {
+            const float *pre = ctx.dry ? nullptr : (const float *)((char *)arena + r[REC_PRE]);
+            const float *mean = ctx.dry ? nullptr : (const float *)((char *)arena + r[REC_MEAN]);
+            const float *invstd = ctx.dry ? nullptr : (const float *)((char *)arena + r[REC_INVSTD]);
+            const bool relu = op[TO_RELU] != 0, has_res = op[TO_RES] >= 0;
+            const bool mask_from_x = relu && !has_res;  // Cout % 4 == 0 checked above
+            const float *ymask = (relu && !mask_from_x) ? bp[out_b] : nullptr;
+            const float *bnw = P<const float>(c[TC_BNW]), *bnb = P<const float>(c[TC_BNB]);
+            double *sums = (double *)sc.take((2 * Cout + 1) * 8);
+            int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
+            double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
+            TRY(lidog_bn_bwd_reduce(gout, pre, ymask, n, Cout, 1, mean, invstd, sums, ws, (double)n, P<float>(c[TC_GBNW]),
+                                    P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr, mask_from_x ? bnb : nullptr,
+                                    stream));
+            float *dx = (float *)ga.take(n * Cout * 4);
+            float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
+            TRY(lidog_bn_bwd_apply(gout, pre, ymask, n, Cout, 1, mean, invstd, bnw, sums, (double)n, dx, dres, nullptr,
+                                   nullptr, mask_from_x ? bnb : nullptr, stream));
+            if (has_res)
+                if (int rc = commit((int)op[TO_RES], dres)) return rc;
+            gout = dx;
+        }
+        // ---- convolution backward (me._SparseConvFn.backward)
+        const float *x = bp[in_b];
+        const int32_t *g_in, *g_out;
+        if (kind == KIND_1X1) {
+            g_in = g_out = P<const int32_t>(m[TM_IDENT]);
+        } else if (kind == KIND_UP) {
+            g_in = P<const int32_t>(m[TM_PAIR_OUT]);
+            g_out = P<const int32_t>(m[TM_PAIR_IN]);
+        } else {
+            g_in = P<const int32_t>(m[TM_PAIR_IN]);
+            g_out = P<const int32_t>(m[TM_PAIR_OUT]);
+        }
+        bool wgrad_done = false;
+        auto queue_wgrad = [&]() -> int {
+            wgrad_done = true;
+            const int n_items = (int)c[TC_NITEMS];
+            int slabs = lidog_sconv_wgrad_slabs(Cin, Cout, n_items);
+            int64_t pbytes = (int64_t)(slabs > 1 ? slabs : 1) * Cin * Cout * 4;
+            float *partial;
+            void *st = stream;
+            if (lane) {
+                ls.reset();
+                partial = (float *)ls.take(pbytes);
+                if (!ctx.dry) {
+                    hipEvent_t ev = events[op[TO_CONV]];
+                    LIDOG_CHECK_HIP(hipEventRecord(ev, main_st));
+                    LIDOG_CHECK_HIP(hipStreamWaitEvent(lane_st, ev, 0));
+                }
+                st = lane;
+                lane_used = 1;
+            } else {
+                partial = (float *)sc.take(pbytes);
+            }
+            TRY(lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
+                                  P<const int32_t>(c[TC_ITEMOFF]), K, Cin, Cout, partial, P<float>(c[TC_GW]), st));
+            return 0;
+        };
+        const bool behind = lane && !wgrad_first;
+        if (!behind)
+            if (int rc = queue_wgrad()) return rc;
+        const bool need_dgrad = bufs[in_b * TB_COLS + TB_EXT] != 0 && kind != KIND_STEM;  // ext slot 0 = input features
+        if (need_dgrad) {
+            const float *Wt = P<const float>(c[TC_WT]);
+            if (!Wt) {
+                float *w = (float *)ga.take((int64_t)K * Cin * Cout * 4);
+                TRY(lidog_transpose_kernel(P<const float>(c[TC_W]), K, Cin, Cout, w, stream));
+                Wt = w;
+            }
+            if (kind == KIND_1X1) {
+                float *gx = target(in_b);
+                if (int rc = gemm(ctx, m, gout, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, stream)) return rc;
+                if (int rc = commit(in_b, gx)) return rc;
+            } else if (kind == KIND_DOWN) {
+                // every fine (input) row has exactly one pair: the GEMM scatters straight into the gradient
+                float *gx = target(in_b);
+                if (int rc = gemm(ctx, m, gout, g_out, Wt, nullptr, Cout, Cin, gx, g_in, stream)) return rc;
+                if (int rc = commit(in_b, gx)) return rc;
+            } else {
+                float *T = (float *)sc.take(m[TM_P] * Cin * 4);
+                if (int rc = gemm(ctx, m, gout, g_out, Wt, nullptr, Cout, Cin, T, nullptr, stream)) return rc;
+                if (!wgrad_done)
+                    if (int rc = queue_wgrad()) return rc;
+                // K3: rows of the input side; UP: the coarse rows are the map's OUTPUT side
+                const int32_t *rp = P<const int32_t>(kind == KIND_UP ? m[TM_RP_OUT] : m[TM_RP_IN]);
+                const int32_t *rl = P<const int32_t>(kind == KIND_UP ? m[TM_RL_OUT] : m[TM_RL_IN]);
+                float *gx = target(in_b);
+                if (op[TO_FOLD] && gs[in_b] != 0) {
+                    // the residual branch's gradient of the block input enters the sum in the reduction's epilogue
+                    TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
+                    gp[in_b] = gx;
+                    gs[in_b] = 2;
+                } else {
+                    TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, nullptr, gx, stream));
+                    if (int rc = commit(in_b, gx)) return rc;
+                }
+            }
+        }
+        if (!wgrad_done)
+            if (int rc = queue_wgrad()) return rc;
+        if (c[TC_BIAS] && c[TC_GBIAS]) {
+            double *ws = (double *)sc.take(lidog_colsum_ws(Cout) * 8);
+            TRY(lidog_colsum(gout, n, Cout, P<float>(c[TC_GBIAS]), ws, stream));
+        }
+    }
+    if (lane_used && !ctx.dry) {
+        hipEvent_t ev = events[n_convs];
+        LIDOG_CHECK_HIP(hipEventRecord(ev, lane_st));
+        LIDOG_CHECK_HIP(hipStreamWaitEvent(main_st, ev, 0));
+    }
+    need[0] = ga.peak;
+    need[1] = sc.peak;
+    need[2] = ls.peak;
+    return 0;
+}

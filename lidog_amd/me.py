@@ -41,26 +41,19 @@ def kernel_offsets(kernel_size, tensor_stride, dilation=1):
 def _tiles_host(k_off_host, skip_k=-1):
     """tile descriptors (tile_k, tile_row0, tile_rows) for 128-row tiles that never straddle an offset:
     (int32 [3, n_tiles] numpy array, n_tiles).  `skip_k`: an offset left out (the centre offset when the reduction
-    pass computes it itself, csrc/sconv_center.hip)"""
-    k_off = np.asarray(k_off_host, dtype=np.int64)
-    cnt = np.diff(k_off)
-    if skip_k >= 0:
-        cnt = cnt.copy()
-        cnt[skip_k] = 0
-    nt = (cnt + TILE_ROWS - 1) // TILE_ROWS
-    total = int(nt.sum())
-    if total == 0:
-        return np.zeros((3, 0), dtype=np.int32), 0
-    tile_k = np.repeat(np.arange(len(cnt), dtype=np.int64), nt)
-    first = np.repeat(np.cumsum(nt) - nt, nt)
-    within = np.arange(total, dtype=np.int64) - first
-    row0 = k_off[tile_k] + within * TILE_ROWS
-    rows = np.minimum(TILE_ROWS, k_off[tile_k + 1] - row0)
-    # Launch order: tiles at the same relative position of their offset segment run together.  Pairs are sorted
-    # by output row inside a segment, so these tiles gather (nearly) the same feature rows for different
-    # offsets while they are still in L2 instead of re-fetching them K times from HBM.
-    order = np.argsort((within + 0.5) / nt[tile_k], kind="stable")
-    return np.stack([tile_k[order], row0[order], rows[order]]).astype(np.int32), total
+    pass computes it itself, csrc/sconv_center.hip).
+    Launch order: tiles at the same relative position of their offset segment run together.  Pairs are sorted by output
+    row inside a segment, so these tiles gather (nearly) the same feature rows for different offsets while they are
+    still in L2 instead of re-fetching them K times from HBM.  (Host code of the library, csrc/hostprep.hip: the numpy
+    formulation cost ~3 ms of python per training step together with the weight-gradient items below.)"""
+    k_off = np.ascontiguousarray(k_off_host, dtype=np.int64)
+    K = k_off.shape[0] - 1
+    cap = int(k_off[-1] - k_off[0]) // TILE_ROWS + K + 1
+    out = np.empty(3 * cap, dtype=np.int32)
+    n = _lib.load().lidog_tiles_host(k_off.ctypes.data, K, int(skip_k), TILE_ROWS, out.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("lidog_tiles_host: capacity")
+    return out[:3 * n].reshape(3, n), int(n)
 
 
 def _tiles(k_off_host, device, skip_k=-1):
@@ -688,26 +681,17 @@ def _wgrad_items_host(k_off_host, chunk):
     runs: pairs are sorted by output row inside an offset, so the items at the same relative position of their
     offsets read (nearly) the same feature and gradient rows -- they are launched together, and in groups that
     land on the same XCD (workgroups go to the 8 XCDs round-robin), so that a row fetched for one offset is still
-    in that XCD's L2 for the others."""
-    k_off = np.asarray(k_off_host, dtype=np.int64)
-    cnt = np.diff(k_off)
-    n_k = (cnt + chunk - 1) // chunk
-    total = int(n_k.sum())
-    item_k = np.repeat(np.arange(len(cnt), dtype=np.int64), n_k)
-    first = np.repeat(np.cumsum(n_k) - n_k, n_k)
-    within = np.arange(total, dtype=np.int64) - first
-    p0 = k_off[item_k] + within * chunk
-    p1 = np.minimum(p0 + chunk, k_off[item_k + 1])
-    order = np.arange(total, dtype=np.int64)
-    if _WGRAD_ORDER >= 1 and total:
-        order = np.argsort((within + 0.5) / n_k[item_k], kind="stable")
-        if _WGRAD_ORDER >= 2:
-            i = np.arange(total, dtype=np.int64)
-            g, j = i // _WGRAD_GROUP, i % _WGRAD_GROUP
-            launch_id = 8 * ((g // 8) * _WGRAD_GROUP + j) + g % 8     # position in the launch sequence
-            order = order[np.argsort(launch_id, kind="stable")]
-    return (np.stack([item_k, p0, p1, order]).astype(np.int32), total,
-            np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32))
+    in that XCD's L2 for the others.  (csrc/hostprep.hip)"""
+    k_off = np.ascontiguousarray(k_off_host, dtype=np.int64)
+    K = k_off.shape[0] - 1
+    cap = int(k_off[-1] - k_off[0]) // int(chunk) + K + 1
+    items = np.empty(4 * cap, dtype=np.int32)
+    item_off = np.empty(K + 1, dtype=np.int32)
+    n = _lib.load().lidog_wgrad_items_host(k_off.ctypes.data, K, int(chunk), _WGRAD_ORDER, _WGRAD_GROUP,
+                                           items.ctypes.data, item_off.ctypes.data, cap)
+    if n < 0:
+        raise RuntimeError("lidog_wgrad_items_host: capacity")
+    return items[:4 * n].reshape(4, n), int(n), item_off
 
 
 def _wgrad_items(m, Cin, Cout):

@@ -31,6 +31,7 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
     BasicBlock = ME.modules.resnet_block.BasicBlock
     _fused = getattr(ME, "bn_relu", None)  # optional backend fast path: BN + ReLU in one kernel
     _conv_bn = getattr(ME, "conv_bn", None)
+    _trunk_exec = getattr(ME, "trunk_forward", None)  # optional: the whole trunk as one launch sequence
 
     class _Trunk(nn.Module):
         BLOCK = BasicBlock
@@ -90,7 +91,11 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
             return self._bn_relu(bn, conv(x))
 
         def _trunk_forward(self, x):
-            """returns (out_block8, out_bottle, {level: tensor})"""
+            """returns (out_block8, out_bottle, {level: tensor}, classifier output or None = not computed yet)"""
+            if _trunk_exec is not None:
+                done = _trunk_exec(self, x)
+                if done is not None:
+                    return done
             out = self._conv_bn_relu(self.conv0p1s1, self.bn0, x)
             skips = [out]
             for i, s in _ENC:
@@ -105,7 +110,7 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
                 out = ME.cat(out, skips.pop())
                 out = getattr(self, f"block{j + 1}")(out)
                 levels[name] = out
-            return out, bottle, levels
+            return out, bottle, levels, None
 
     class MinkUNet34(_Trunk):
         def __init__(self, in_channels, out_channels, D=3, initial_kernel_size=5):
@@ -114,8 +119,9 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
             self.weight_initialization()
 
         def forward(self, x, is_seg=True):
-            out, _, _ = self._trunk_forward(x)
-            return self.final(out) if is_seg else (self.final(out), out)
+            out, _, _, seg = self._trunk_forward(x)
+            seg = seg if seg is not None else self.final(out)
+            return seg if is_seg else (seg, out)
 
     class MinkUNet34BEV(_Trunk):
         def __init__(self, in_channels, out_channels, D, initial_kernel_size=5, dynamic_mapping=False,
@@ -132,7 +138,7 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
             self.weight_initialization()
 
         def forward(self, x, is_seg=True, is_train=False):
-            out, bottle, levels = self._trunk_forward(x)
+            out, bottle, levels, seg = self._trunk_forward(x)
             img_pred = None
             if is_train:
                 img_pred = {}
@@ -140,8 +146,9 @@ def make_models(ME, Encoder2D=None, sparse2super=None):
                     stride = int(3 / self.scaling_factors[key])
                     bev = sparse2super(levels[key], bound=self.mapping_bound_2d, voxel=0.05, pool=(5, stride, 1))
                     img_pred[key] = self.encoders2d[key](bev)
+            seg = seg if seg is not None else self.final(out)
             if is_seg:
-                return self.final(out), img_pred
-            return self.final(out), img_pred, bottle, None
+                return seg, img_pred
+            return seg, img_pred, bottle, None
 
     return types.SimpleNamespace(MinkUNet34=MinkUNet34, MinkUNet34BEV=MinkUNet34BEV)

@@ -60,8 +60,10 @@ class FlatParams:
         """gradients that autograd produced outside the flat buffer (e.g. a bias gradient from a torch op) are
         copied in with one fused call; returns how many there were"""
         dst, src = [], []
+        base = self.grad.data_ptr()
         for p, off in zip(self.params, self.offsets):
-            if p.grad is not None and not self.in_place(p, off):
+            g = p.grad
+            if g is not None and g.data_ptr() != base + 4 * off:
                 view = self.grad[off:off + p.numel()].view(p.shape)
                 dst.append(view)
                 src.append(p.grad)

@@ -212,6 +212,15 @@ def test_model_called_twice_before_one_backward():
 
 # ------------------------------------------------------------------ two data-parallel ranks == one rank, joint batch
 def _dp_worker(rank, world, port, q):
+    try:
+        _dp_worker_body(rank, world, port, q)
+    except Exception as e:   # report instead of dying silently: the peer would sit in its barrier until the timeout
+        import traceback
+        q.put((rank, False, f"{e!r}\n{traceback.format_exc()}"))
+        raise
+
+
+def _dp_worker_body(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, REPO)
@@ -255,8 +264,8 @@ def _dp_worker(rank, world, port, q):
         ropt = FlatAdam(ref, lr=1e-3, weight_decay=1e-4, local=True)
         both = data.batch([0, 1], "cuda")
         x = ME.SparseTensor(coordinates=both["coords_int"], features=both["source_features0"])
-        out, _, levels = ref._trunk_forward(x)
-        logits = ref.final(out).F
+        out, _, levels, seg = ref._trunk_forward(x)
+        logits = (seg if seg is not None else ref.final(out)).F
         lv = levels["block8"]
         sem_c, bev_c = SoftDICELoss(ignore_label=-1), DICELoss(ignore_label=-1)
         tot = 0.0
@@ -302,7 +311,11 @@ def test_lidog_step_two_ranks_equal_one_rank_on_the_joint_batch():
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]
+    failed = not all(ok for _, ok, _ in got)
     for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert all(ok for _, ok, _ in got), got
+        p.join(10 if failed else 120)
+        if p.is_alive():     # a rank whose peer failed waits in the barrier: end exactly that process
+            p.terminate()
+            p.join(30)
+    assert not failed, got
+    assert all(p.exitcode == 0 for p in procs)
