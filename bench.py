@@ -49,7 +49,21 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
-        self.enabled = False
+        self._enabled = False
+        self.native = [0.0, 0.0, 0.0, 0.0]   # launches, ms, FLOPs, bytes timed inside the trunk executor
+
+    @property
+    def enabled(self):
+        return self._enabled
+
+    @enabled.setter
+    def enabled(self, on):
+        # the training step's convolutions are launched by the trunk executor (csrc/trunk.hip): its launches of the
+        # same kernel are bracketed by events in C, on the stream they run on (lidog_trunk_gemm_timing)
+        if bool(on) != self._enabled:
+            from lidog_amd import _lib
+            _lib.load().lidog_trunk_gemm_timing(1 if on else 0)
+        self._enabled = bool(on)
 
     def wrap(self, me):
         orig = me._gemm
@@ -71,12 +85,19 @@ class GemmTimer:
         me._gemm = timed
 
     def summary(self):
-        if not self.records:
+        import ctypes
+        from lidog_amd import _lib
+        buf = (ctypes.c_double * 4)()
+        if _lib.load().lidog_trunk_gemm_timing_read(buf) != 0:
+            raise RuntimeError(_lib.load().lidog_last_error().decode())
+        self.native = [a + b for a, b in zip(self.native, buf)]
+        n = len(self.records) + int(self.native[0])
+        if not n:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
-        by = sum(r[2] for r in self.records)
-        fl = sum(r[3] for r in self.records)
-        return dict(launches=len(self.records), total_ms=ms, bytes=by, flops=fl)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records) + self.native[1]
+        by = sum(r[2] for r in self.records) + self.native[3]
+        fl = sum(r[3] for r in self.records) + self.native[2]
+        return dict(launches=n, total_ms=ms, bytes=by, flops=fl)
 
 
 def cpu_baseline(config, steps_budget_s=30.0, threads=None):

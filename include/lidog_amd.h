@@ -395,6 +395,11 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
                          int64_t scratch_bytes, void *lane_scratch, int64_t lane_bytes, int64_t *need /*[3]*/,
                          int32_t *conv_done_host /*[n_convs]: 1 = this convolution's parameter gradients were written*/,
                          int32_t dry, int32_t wgrad_first, void *stream, void *lane);
+/* Timing of the executor's gathered-GEMM launches for the roofline figure of bench.py: on != 0 brackets every such
+ * launch with HIP events on its stream; _read waits for the recorded launches, returns (launches, total ms, algorithmic
+ * FLOPs, algorithmic bytes: SURVEY.md 8(d)) in out[0..3] and forgets them.  One timing client per process. */
+int lidog_trunk_gemm_timing(int32_t on);
+int lidog_trunk_gemm_timing_read(double *out /*[4]*/);
 
 #ifdef __cplusplus
 }

@@ -248,8 +248,12 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
     if (colreduce_uses_partials(C, hw)) {
         LIDOG_REQUIRE(ws != nullptr, "bn reduce: workspace of lidog_bn_reduce_ws() doubles required");
         int C4 = C / 4, RB = 256 / C4;
-        // 2 workgroups per CU, 4 rows in flight per lane: enough loads in flight to stream
-        int64_t nb = cdiv64(n, (int64_t)RB * 16);
+        // 2 workgroups per CU, 4 rows in flight per lane: enough loads in flight to stream; small inputs get one
+        // round of 4 rows per lane instead of four (the rounds of a lane are serial: latency, not bandwidth)
+#ifndef COLREDUCE_ROUNDS
+#define COLREDUCE_ROUNDS 1   // rounds of 4 rows per lane before the grid is capped (A/B switch; was 4)
+#endif
+        int64_t nb = cdiv64(n, (int64_t)RB * 4 * COLREDUCE_ROUNDS);
         if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
         k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
                                                             n, C4, mean, invstd, ws, rw, rb);

@@ -608,7 +608,14 @@ extern "C" int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_
     LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_reduce_rows_stats: finalising needs the row count");
     if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     int C4 = C / 4, RB = 256 / C4;
-    int64_t nb = cdiv64(n, (int64_t)RB * 4);
+    // one row per thread until the partial-sum table is full (2048 workgroups), then a grid-stride loop: a row's walk
+    // is a chain of three dependent loads (row_ptr -> row_list -> product rows), and rows handled by the same thread run
+    // one after the other -- on the small maps (deep layers, 8 k-point scans) four rows per thread were 4 x that latency
+    // with the chip nearly empty (18 us instead of 8)
+#ifndef RED_STATS_ROWS
+#define RED_STATS_ROWS 1   // rows per thread before the grid-stride loop takes over (A/B switch; was 4)
+#endif
+    int64_t nb = cdiv64(n, (int64_t)RB * RED_STATS_ROWS);
     if (nb > 2048) nb = 2048;
     k_sconv_reduce_rows4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, row_ptr, row_list, n, C4,
                                                              (const float4 *)bias, (float4 *)out, partial_ws);

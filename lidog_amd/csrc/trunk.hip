@@ -149,10 +149,49 @@ int check_tables(const Ctx &ctx, bool grads) {
 
 inline const int32_t *tile_row(const int64_t *m, int r) { return P<const int32_t>(m[TM_TILES]) + r * m[TM_NTILES]; }
 
-int gemm(const Ctx &ctx, const int64_t *m, const float *A, const int32_t *gather, const float *B, const float *bias,
-         int Cin, int Cout, float *out, const int32_t *scatter, void *st) {
-    TRY(lidog_sconv_gemm(A, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2), (int32_t)m[TM_NTILES], Cin,
-                         Cout, out, scatter, st));
+// Optional timing of the gathered GEMM's launches (bench.py's roofline figure): HIP events on the launch stream around
+// every lidog_sconv_gemm call of the executor, with the launch's algorithmic FLOPs and bytes (every distinct input row
+// and weight read once, every product row written once, the gather index read once: SURVEY.md 8(d)).
+struct GemmRec {
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+bool g_timing = false;
+std::vector<GemmRec> g_recs;
+std::vector<hipEvent_t> g_spare;
+
+hipEvent_t timing_event() {
+    hipEvent_t e = nullptr;
+    if (!g_spare.empty()) {
+        e = g_spare.back();
+        g_spare.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
+
+// n_src: rows of A (the gathered matrix)
+int gemm(const Ctx &ctx, const int64_t *m, const float *A, int64_t n_src, const int32_t *gather, const float *B,
+         const float *bias, int Cin, int Cout, float *out, const int32_t *scatter, void *st) {
+    if (ctx.dry) return 0;
+    GemmRec rec{nullptr, nullptr, 0, 0};
+    if (g_timing) {
+        rec.e0 = timing_event();
+        rec.e1 = timing_event();
+        LIDOG_REQUIRE(rec.e0 && rec.e1, "trunk: cannot create timing events");
+        const double rows = (double)m[TM_P], src = (double)(n_src < m[TM_P] ? n_src : m[TM_P]);
+        rec.flops = 2.0 * rows * Cin * Cout;
+        rec.bytes = 4.0 * (src * Cin + rows * Cout + (double)m[TM_K] * Cin * Cout) + 4.0 * rows;
+        LIDOG_CHECK_HIP(hipEventRecord(rec.e0, (hipStream_t)st));
+    }
+    int rc = lidog_sconv_gemm(A, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2), (int32_t)m[TM_NTILES],
+                              Cin, Cout, out, scatter, st);
+    if (rc) return rc;
+    if (g_timing) {
+        LIDOG_CHECK_HIP(hipEventRecord(rec.e1, (hipStream_t)st));
+        g_recs.push_back(rec);
+    }
     return 0;
 }
 
@@ -224,7 +263,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         if (kind == KIND_K3 || kind == KIND_DOWN) {
             // gathered GEMM into product rows, per-row reduction (+ BatchNorm statistics in its epilogue)
             float *T = (float *)sc.take(m[TM_P] * Cout * 4);
-            if (int rc = gemm(ctx, m, x, P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T, nullptr, stream))
+            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T, nullptr, stream))
                 return rc;
             const int32_t *rp = P<const int32_t>(m[TM_RP_OUT]), *rl = P<const int32_t>(m[TM_RL_OUT]);
             if (bn) {
@@ -238,11 +277,11 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             }
         } else if (kind == KIND_UP) {
             // transposed 2^3 stride 2: every fine row has exactly one pair, the GEMM scatters straight into the output
-            if (int rc = gemm(ctx, m, x, P<const int32_t>(m[TM_PAIR_OUT]), W, bias, Cin, Cout, pre,
+            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_OUT]), W, bias, Cin, Cout, pre,
                               P<const int32_t>(m[TM_PAIR_IN]), stream))
                 return rc;
         } else if (kind == KIND_1X1) {
-            if (int rc = gemm(ctx, m, x, nullptr, W, bias, Cin, Cout, pre, nullptr, stream)) return rc;
+            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), nullptr, W, bias, Cin, Cout, pre, nullptr, stream)) return rc;
         } else {
             TRY(lidog_sconv_cin1(x, P<const int32_t>(m[TM_NBR]), W, bias, n, K, Cout, pre, stream));
         }
@@ -422,16 +461,16 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             }
             if (kind == KIND_1X1) {
                 float *gx = target(in_b);
-                if (int rc = gemm(ctx, m, gout, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, stream)) return rc;
+                if (int rc = gemm(ctx, m, gout, n, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, stream)) return rc;
                 if (int rc = commit(in_b, gx)) return rc;
             } else if (kind == KIND_DOWN) {
                 // every fine (input) row has exactly one pair: the GEMM scatters straight into the gradient
                 float *gx = target(in_b);
-                if (int rc = gemm(ctx, m, gout, g_out, Wt, nullptr, Cout, Cin, gx, g_in, stream)) return rc;
+                if (int rc = gemm(ctx, m, gout, n, g_out, Wt, nullptr, Cout, Cin, gx, g_in, stream)) return rc;
                 if (int rc = commit(in_b, gx)) return rc;
             } else {
                 float *T = (float *)sc.take(m[TM_P] * Cin * 4);
-                if (int rc = gemm(ctx, m, gout, g_out, Wt, nullptr, Cout, Cin, T, nullptr, stream)) return rc;
+                if (int rc = gemm(ctx, m, gout, n, g_out, Wt, nullptr, Cout, Cin, T, nullptr, stream)) return rc;
                 if (!wgrad_done)
                     if (int rc = queue_wgrad()) return rc;
                 // K3: rows of the input side; UP: the coarse rows are the map's OUTPUT side
@@ -464,5 +503,30 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     need[0] = ga.peak;
     need[1] = sc.peak;
     need[2] = ls.peak;
+    return 0;
+}
+
+// Timing of the executor's gathered-GEMM launches (see GemmRec above).  on != 0: every launch from now on is bracketed
+// by events; lidog_trunk_gemm_timing_read waits for the recorded launches and returns (launches, total ms, algorithmic
+// FLOPs, algorithmic bytes) in out[0..3], then forgets them.  Not thread-safe: one timing client per process.
+extern "C" int lidog_trunk_gemm_timing(int32_t on) {
+    g_timing = on != 0;
+    return 0;
+}
+
+extern "C" int lidog_trunk_gemm_timing_read(double *out) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (GemmRec &r : g_recs) {
+        float ms = 0;
+        LIDOG_CHECK_HIP(hipEventSynchronize(r.e1));
+        LIDOG_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        out[0] += 1;
+        out[1] += ms;
+        out[2] += r.flops;
+        out[3] += r.bytes;
+        g_spare.push_back(r.e0);
+        g_spare.push_back(r.e1);
+    }
+    g_recs.clear();
     return 0;
 }

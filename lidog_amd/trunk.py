@@ -8,7 +8,7 @@ arguments, hence bit-identical results (tests/test_gpu_trunk.py) -- behind a sin
 
 The executor takes the training step of a model whose trunk is built from the modules of lidog_amd.me with local
 BatchNorm statistics.  Everything else (evaluation mode, no_grad, SyncBatchNorm with a process group, frozen
-parameters, a second call of the model before backward, LIDOG_TRUNK_EXEC=0) stays on the operator path.
+parameters, LIDOG_TRUNK_EXEC=0) stays on the operator path.
 """
 import os
 import weakref
@@ -218,13 +218,6 @@ def _eligible(model, prog, x):
     for p in prog.params:
         if not p.requires_grad or p.dtype != torch.float32 or not p.is_cuda:
             return False
-    # one executor pass per model and gradient generation: a second call before backward (the reference's
-    # multi-source pipelines, trainer_lighting_2d_multi.py:166-167) goes through the operator path and accumulates
-    ref = getattr(prog.params[0], "_flat_ref", None)
-    if ref is not None:
-        claim = (id(ref[2]), ref[2].generation)
-        if model.__dict__.get("_lidog_trunk_claim") == claim:
-            return False
     return True
 
 
@@ -368,9 +361,17 @@ class _TrunkFn(torch.autograd.Function):
         # where the parameter gradients go: the optimiser's flat buffer (me._grad_out) when this pass owns the slice,
         # else one fresh buffer for the rest
         convs = run.convs
+        # A slice of the flat buffer is handed out at most once per gradient generation (me._grad_out): when the
+        # model is called twice before one backward pass (trainer_lighting_2d_multi.py:166-167) the pass that runs
+        # second computes into fresh tensors and autograd accumulates; this call has joined the lane by then.
         flat = _flat_targets(prog)
-        direct = flat is not None and len(run.claimed) == len(prog.params) and \
-            flat[0].generation == run.generation and all(p.grad is None for p in prog.params)
+        direct = False
+        if flat is not None:
+            gen = flat[0].generation
+            direct = all(p.grad is None and p._flat_taken != gen for p in prog.params)
+            if direct:
+                for p in prog.params:
+                    p._flat_taken = gen
         if direct:
             # the common case: every gradient goes straight into the flat buffer through views made once; they are
             # bound to .grad below, by hand (188 AccumulateGrad nodes would only do the same assignment)
@@ -380,7 +381,8 @@ class _TrunkFn(torch.autograd.Function):
             views, fresh = [None] * len(prog.params), []
             for i, p in enumerate(prog.params):
                 ref = getattr(p, "_flat_ref", None)
-                if ref is not None and p.grad is None and id(p) in run.claimed and p._flat_taken == ref[2].generation:
+                if ref is not None and p.grad is None and p._flat_taken != ref[2].generation:
+                    p._flat_taken = ref[2].generation
                     views[i] = ref[0][ref[1]:ref[1] + p.numel()].view(p.shape)
                 else:
                     fresh.append(i)
@@ -438,18 +440,6 @@ def trunk_forward(model, x):
         return None
     cm = x.coordinate_manager
     cm.trace.extend(prog.trace)
-    # claim the flat-buffer slices of the trunk's parameters for this pass (me._grad_out hands a slice out once per
-    # generation; a later operator-path use of the same parameter accumulates into it)
-    run.claimed = set()
-    ref0 = getattr(prog.params[0], "_flat_ref", None)
-    run.generation = ref0[2].generation if ref0 is not None else -1
-    for p in prog.params:
-        ref = getattr(p, "_flat_ref", None)
-        if ref is not None and p.grad is None and p._flat_taken != ref[2].generation:
-            p._flat_taken = ref[2].generation
-            run.claimed.add(id(p))
-    if ref0 is not None:
-        model.__dict__["_lidog_trunk_claim"] = (id(ref0[2]), ref0[2].generation)
     feats = x.F.contiguous()
     out, logits, bottle, lv_bottle, lv6, lv7 = _TrunkFn.apply(feats, run, *prog.params)
 
