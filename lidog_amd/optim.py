@@ -31,6 +31,7 @@ class FlatParams:
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets = []
         self.generation = 0
+        self.hooked = False
         off = 0
         for p in self.params:
             n = p.numel()
@@ -130,6 +131,7 @@ class GradientBuckets:
         self.pending = list(self.pending0)
         for p in flat.params:
             p.register_post_accumulate_grad_hook(self._hook)
+        flat.hooked = True     # gradients must reach .grad through autograd (lidog_amd.trunk binds them by hand otherwise)
 
     def _close(self, members, lo, hi, count):
         b = len(self.slices)

@@ -417,11 +417,14 @@ class _TrunkFn(torch.autograd.Function):
         run.done = True
         grads = [None] * len(prog.params)
         params = prog.params
+        # gradient hooks on the parameters (the data-parallel buckets of lidog_amd.optim.GradientBuckets): the gradients
+        # go back through autograd so that the hooks fire
+        bind = direct and not flat[0].hooked
         for ci, slot in enumerate(prog.slots):
             if done[ci]:
                 for s in slot:
                     if s >= 0:
-                        if direct:
+                        if bind:
                             params[s].grad = views[s]
                         else:
                             grads[s] = views[s]

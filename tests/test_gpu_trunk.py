@@ -85,7 +85,7 @@ def _forward_backward(model, batch, with_seg=True, with_bev=True):
     if with_bev:
         loss = loss + DICELoss(ignore_label=-1)(bev["block8"].view(-1, 7), batch["source_bev_labels0"]["block8"].view(-1))
     loss.backward()
-    return sem.F.detach().clone(), float(loss)
+    return sem.F.detach().clone(), float(loss.detach())
 
 
 @pytest.mark.parametrize("with_seg,with_bev", [(True, True), (False, True), (True, False)])
@@ -214,3 +214,73 @@ def test_executor_at_the_bench_shape_matches_the_operator_path():
     assert res[True][0] == res[False][0]
     _assert_same(res[True][1], res[False][1], "gradient")
     _assert_same(res[True][2], res[False][2], "state")
+
+
+# ------------------------------------------------------------------ data parallel without SyncBatchNorm: hooks must fire
+def _dp_plain_worker(rank, world, port, q):
+    import os
+    import sys
+    import traceback
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from helpers import REPO
+        sys.path.insert(0, REPO)
+        torch.cuda.set_device(0)
+        from lidog_amd import trunk
+        from lidog_amd.optim import FlatAdam
+        batch = _batch((81 + rank, 91 + rank))
+        # (a) executor + gradient buckets of the process group (plain BatchNorm: the executor applies)
+        model = _model()
+        opt = FlatAdam(model, lr=1e-3, bucket_bytes=8 << 20)
+        assert opt.buckets.active and opt.flat.hooked
+        import lidog_amd.me as ME
+        opt.zero_grad()
+        sem, _ = model(ME.SparseTensor(coordinates=batch["coords_int"], features=batch["source_features0"]),
+                       is_train=True)
+        assert type(sem.F.grad_fn).__name__ == "_TrunkFnBackward"
+        sem.F.square().mean().backward()
+        opt._prepare()
+        torch.cuda.synchronize()
+        got = opt.flat.grad.clone()
+        # (b) operator path, no data parallelism, summed by hand
+        trunk.set_enabled(False)
+        ref = _model()
+        ropt = FlatAdam(ref, lr=1e-3, local=True)
+        ropt.zero_grad()
+        sem, _ = ref(ME.SparseTensor(coordinates=batch["coords_int"], features=batch["source_features0"]),
+                     is_train=True)
+        sem.F.square().mean().backward()
+        ropt._prepare()
+        torch.cuda.synchronize()
+        want = ropt.flat.grad.clone()
+        dist.all_reduce(want)
+        ok = torch.equal(got, want)
+        q.put((rank, ok, "" if ok else f"max |diff| {(got - want).abs().max().item():.3e}"))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, False, f"{e!r}\n{traceback.format_exc()}"))
+        raise
+
+
+def test_executor_under_plain_data_parallel_fires_the_gradient_hooks():
+    """DDP without SyncBatchNorm (local statistics): the executor runs, its gradients go through autograd so that the
+    bucket hooks reduce them: flat gradient == sum over ranks of the operator path's local gradients, bit for bit"""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_plain_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    failed = not all(ok for _, ok, _ in got)
+    for p in procs:
+        p.join(10 if failed else 60)
+        if p.is_alive():
+            p.terminate()
+            p.join(30)
+    assert not failed, got
