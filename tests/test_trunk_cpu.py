@@ -1,0 +1,137 @@
+"""Trunk executor without a GPU: the static program built from the model (lidog_amd/trunk.py) and the C walk in dry
+mode (csrc/trunk.hip: table checks, memory plan, which convolutions receive gradients).  No kernel is launched."""
+import ctypes
+
+import numpy as np
+import pytest
+
+
+def _tables(prog, levels):
+    """per-batch tables with placeholder addresses (dry runs never dereference them)"""
+    from lidog_amd import trunk
+    A = 4096
+    maps = np.zeros((len(prog.map_keys), trunk.TM_COLS), np.int64)
+    for i, key in enumerate(prog.map_keys):
+        if key[0] == "identity":
+            n = levels[int(np.log2(key[1]))]
+            maps[i, :14] = [1, n, n, n, 0, 0, 0, 0, 0, 0, A, (n + 127) // 128, 0, A]
+        else:
+            s_in, s_out, ks, _ = key
+            n_in, n_out = levels[int(np.log2(s_in))], levels[int(np.log2(s_out))]
+            K = ks ** 3
+            P = n_out * 4 if ks == 3 else (n_in if ks == 2 else n_out * 20)
+            maps[i, :14] = [K, n_in, n_out, P, A, A, A, A, A, A, A, (P + 127) // 128 + K, A, 0]
+    convs = np.zeros((len(prog.convs), trunk.TC_COLS), np.int64)
+    for i, (cv, bnm, kind, _, _) in enumerate(prog.convs):
+        K = 1 if kind == trunk.KIND_1X1 else cv.kernel_volume
+        b = A if cv.bias is not None else 0
+        row = [kind, prog.conv_map[i], cv.in_channels, cv.out_channels, K, A, A, A, b, b] + \
+              ([A] * 6 if bnm is not None else [0] * 6) + [A, 64, A]
+        convs[i, :len(row)] = row
+    return maps, convs, np.zeros((len(prog.convs), 2))
+
+
+@pytest.fixture(scope="module")
+def prog():
+    import lidog_amd
+    from lidog_amd import trunk
+    model = lidog_amd.MinkUNet34BEV(1, 7, 3)
+    p = trunk.program_of(model)
+    assert p is not None
+    return p
+
+
+def test_program_mirrors_the_model(prog):
+    from lidog_amd import trunk
+    assert len(prog.convs) == 63 and len(prog.bns) == 62 and len(prog.params) == 188
+    ops = prog.ops
+    assert (ops[:, trunk.TO_COLS - 8] == trunk.OP_CAT).sum() == 4      # 4 skip concatenations
+    assert (ops[:, 0] == trunk.OP_CONV).sum() == 1                      # the classifier
+    kinds = [k for _, _, k, _, _ in prog.convs]
+    assert kinds.count(trunk.KIND_STEM) == 1 and kinds.count(trunk.KIND_DOWN) == 4 and kinds.count(trunk.KIND_UP) == 4
+    assert kinds.count(trunk.KIND_1X1) == 7 + 1                         # 7 downsample branches + classifier
+    assert kinds.count(trunk.KIND_K3) == 2 * 23
+    # every buffer except the input is written exactly once, before it is read
+    written = {0}
+    for op in ops:
+        reads = [op[2]] + ([op[7]] if op[0] == trunk.OP_CAT else []) + ([op[5]] if op[5] >= 0 else [])
+        assert all(r in written for r in reads)
+        assert op[3] not in written
+        written.add(op[3])
+    assert written == set(range(len(prog.bufs)))
+    # the trace equals what the operator path records (one entry per convolution, forward order)
+    assert len(prog.trace) == 63 and prog.trace[0] == ((1, 1, 5, 1), 1, 32) and prog.trace[-1][0] == ("identity", 1)
+    # external tensors: block8 features, logits, bottleneck and the three other decoder levels
+    assert sorted(prog.ext_shape) == [1, 2, 3, 4, 5, 6]
+    assert prog.ext_shape[trunk.EXT_LOGITS] == (0, 7) and prog.ext_shape[trunk.EXT_BOTTLE] == (4, 256)
+
+
+def _dry(prog, levels, ext_grad, lane=True):
+    from lidog_amd import _lib
+    L = _lib.load()
+    lv = np.array(levels, np.int64)
+    maps, convs, conv_f = _tables(prog, levels)
+    ext = np.full(7, 4096, np.int64)
+    rec = np.zeros(prog.n_rec, np.int64)
+    need_f, need_b = np.zeros(2, np.int64), np.zeros(3, np.int64)
+    done = np.zeros(len(convs), np.int32)
+    common = (convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps), prog.ops.ctypes.data,
+              len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs), lv.ctypes.data, ext.ctypes.data)
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need_f.ctypes.data, 1, None)
+    assert rc == 0, L.lidog_last_error()
+    eg = np.array(ext_grad, np.int64)
+    rc = L.lidog_trunk_backward(*common, eg.ctypes.data, None, rec.ctypes.data, None, 0, None, 0, None, 0,
+                                need_b.ctypes.data, done.ctypes.data, 1, 0, None, ctypes.c_void_p(4096 if lane else 0))
+    assert rc == 0, L.lidog_last_error()
+    return need_f, need_b, done, common, (rec, lv, maps, convs, conv_f, ext)   # the arrays `common` points into
+
+
+def test_dry_run_plans_memory_and_gradient_reach(prog):
+    small, big = [20000, 12000, 6000, 2500, 900], [352000, 207000, 102000, 41000, 15000]
+    both = [0, 4096, 4096, 0, 0, 0, 0]
+    f_s, b_s, done, _, _ = _dry(prog, small, both)
+    f_b, b_b, _, _, _ = _dry(prog, big, both)
+    assert done.all()
+    assert (f_b > f_s).all() and (b_b[:2] > b_s[:2]).all()
+    assert 4.5e9 < f_b[0] < 6e9 and b_b[0] < 8e9            # ~5 GB of activations, ~6.5 GB of gradients at the bench shape
+    # weight gradients in line: their partial slots come out of the main scratch, none on the lane
+    _, b_inline, _, _, _ = _dry(prog, small, both, lane=False)
+    assert b_inline[2] == 0 and b_inline[1] >= b_s[1]
+    # warm-up epochs: no classifier gradient -> the classifier is skipped, everything else still runs
+    _, _, done, _, _ = _dry(prog, small, [0, 4096, 0, 0, 0, 0, 0])
+    assert done[-1] == 0 and done[:-1].all()
+    # segmentation loss only: block8's gradient comes from the classifier alone
+    _, _, done, _, _ = _dry(prog, small, [0, 0, 4096, 0, 0, 0, 0])
+    assert done.all()
+    # nothing reaches the trunk: nothing to do
+    _, _, done, _, _ = _dry(prog, small, [0] * 7)
+    assert not done.any()
+
+
+def test_real_run_refuses_regions_that_are_too_small(prog):
+    from lidog_amd import _lib
+    L = _lib.load()
+    levels = [20000, 12000, 6000, 2500, 900]
+    need_f, _, _, common, keep = _dry(prog, levels, [0, 4096, 4096, 0, 0, 0, 0])
+    rec = keep[0]
+    need = np.zeros(2, np.int64)
+    # one byte short of the plan: refused before anything is launched (no GPU is touched on this path)
+    rc = L.lidog_trunk_forward(*common, ctypes.c_void_p(4096), int(need_f[0]) - 1, ctypes.c_void_p(4096), int(need_f[1]),
+                               rec.ctypes.data, need.ctypes.data, 0, None)
+    assert rc != 0 and b"arena" in L.lidog_last_error()
+
+
+def test_tables_are_checked(prog):
+    from lidog_amd import _lib, trunk
+    L = _lib.load()
+    levels = [20000, 12000, 6000, 2500, 900]
+    lv = np.array(levels, np.int64)
+    maps, convs, conv_f = _tables(prog, levels)
+    maps[2, trunk.TM_COLS - 14] += 1          # n_in of the first 3^3 map no longer matches its buffers
+    ext = np.full(7, 4096, np.int64)
+    rec, need = np.zeros(prog.n_rec, np.int64), np.zeros(2, np.int64)
+    rc = L.lidog_trunk_forward(convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps),
+                               prog.ops.ctypes.data, len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs),
+                               lv.ctypes.data, ext.ctypes.data, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1,
+                               None)
+    assert rc != 0 and b"rows" in L.lidog_last_error()
