@@ -73,6 +73,22 @@ inline T *P(int64_t v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v))
         }                         \
     } while (0)
 
+#ifdef TRUNK_EXP_SKIP   // timing experiments (results are garbage): LIDOG_TRUNK_SKIP = bit mask of kernel families left out
+#include <stdlib.h>
+static int exp_skip() {
+    static int v = -1;
+    if (v < 0) v = getenv("LIDOG_TRUNK_SKIP") ? atoi(getenv("LIDOG_TRUNK_SKIP")) : 0;
+    return v;
+}
+#define TRYX(bit, expr)                      \
+    do {                                     \
+        if (!(exp_skip() & (bit))) TRY(expr); \
+    } while (0)
+static int g_gemm_bit = 1;
+#else
+#define TRYX(bit, expr) TRY(expr)
+#endif
+
 // events for forking the lane stream behind the main stream (one per convolution) and joining it again
 hipEvent_t *event_pool(int n) {
     static std::vector<hipEvent_t> pool;
@@ -175,6 +191,9 @@ hipEvent_t timing_event() {
 int gemm(const Ctx &ctx, const int64_t *m, const float *A, int64_t n_src, const int32_t *gather, const float *B,
          const float *bias, int Cin, int Cout, float *out, const int32_t *scatter, void *st) {
     if (ctx.dry) return 0;
+#ifdef TRUNK_EXP_SKIP
+    if (exp_skip() & g_gemm_bit) return 0;   // 1 = forward GEMMs, 32 = data-gradient GEMMs
+#endif
     GemmRec rec{nullptr, nullptr, 0, 0};
     if (g_timing) {
         rec.e0 = timing_event();
@@ -217,6 +236,9 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                       (long long)want[1], (long long)arena_bytes, (long long)scratch_bytes);
     }
     Bump ar{(char *)arena, 0, arena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry};
+#ifdef TRUNK_EXP_SKIP
+    g_gemm_bit = 1;
+#endif
     int64_t *buf_off = rec + (int64_t)n_ops * REC_COLS;
     // activation buffers: external ones are the caller's tensors, the others live in the arena
     std::vector<float *> bp(n_bufs, nullptr);
@@ -269,7 +291,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             if (bn) {
                 double *sums = (double *)sc.take((2 * Cout + 1) * 8);
                 double *ws = (double *)sc.take(lidog_sconv_reduce_stats_ws(n, Cout) * 8);
-                TRY(lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, eps, mom, mean,
+                TRYX(2, lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, eps, mom, mean,
                                                   invstd, rm, rv, stream));
                 stats_done = true;
             } else {
@@ -290,10 +312,10 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             double *sums = (double *)sc.take((2 * Cout + 1) * 8);
             int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
             double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-            TRY(lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, eps, mom, mean, invstd, rm, rv, stream));
+            TRYX(4, lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, eps, mom, mean, invstd, rm, rv, stream));
         }
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
-        TRY(lidog_bn_apply(pre, n, Cout, 1, mean, invstd, P<const float>(c[TC_BNW]), P<const float>(c[TC_BNB]), res,
+        TRYX(4, lidog_bn_apply(pre, n, Cout, 1, mean, invstd, P<const float>(c[TC_BNW]), P<const float>(c[TC_BNB]), res,
                            (int32_t)op[TO_RELU], y, stream));
     }
     need[0] = ar.peak;
@@ -331,6 +353,9 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     Bump ga{(char *)garena, 0, garena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry},
         ls{(char *)lane_scratch, 0, lane_bytes, 0, ctx.dry};
     hipStream_t main_st = (hipStream_t)stream, lane_st = (hipStream_t)lane;
+#ifdef TRUNK_EXP_SKIP
+    g_gemm_bit = 32;
+#endif
     hipEvent_t *events = nullptr;
     if (lane && !ctx.dry) {
         events = event_pool(n_convs + 1);
@@ -400,12 +425,12 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             double *sums = (double *)sc.take((2 * Cout + 1) * 8);
             int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
             double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-            TRY(lidog_bn_bwd_reduce(gout, pre, ymask, n, Cout, 1, mean, invstd, sums, ws, (double)n, P<float>(c[TC_GBNW]),
+            TRYX(8, lidog_bn_bwd_reduce(gout, pre, ymask, n, Cout, 1, mean, invstd, sums, ws, (double)n, P<float>(c[TC_GBNW]),
                                     P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr, mask_from_x ? bnb : nullptr,
                                     stream));
             float *dx = (float *)ga.take(n * Cout * 4);
             float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
-            TRY(lidog_bn_bwd_apply(gout, pre, ymask, n, Cout, 1, mean, invstd, bnw, sums, (double)n, dx, dres, nullptr,
+            TRYX(16, lidog_bn_bwd_apply(gout, pre, ymask, n, Cout, 1, mean, invstd, bnw, sums, (double)n, dx, dres, nullptr,
                                    nullptr, mask_from_x ? bnb : nullptr, stream));
             if (has_res)
                 if (int rc = commit((int)op[TO_RES], dres)) return rc;
@@ -444,7 +469,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             } else {
                 partial = (float *)sc.take(pbytes);
             }
-            TRY(lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
+            TRYX(128, lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
                                   P<const int32_t>(c[TC_ITEMOFF]), K, Cin, Cout, partial, P<float>(c[TC_GW]), st));
             return 0;
         };
@@ -479,11 +504,11 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 float *gx = target(in_b);
                 if (op[TO_FOLD] && gs[in_b] != 0) {
                     // the residual branch's gradient of the block input enters the sum in the reduction's epilogue
-                    TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
+                    TRYX(64, lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
                     gp[in_b] = gx;
                     gs[in_b] = 2;
                 } else {
-                    TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, nullptr, gx, stream));
+                    TRYX(64, lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, nullptr, gx, stream));
                     if (int rc = commit(in_b, gx)) return rc;
                 }
             }
