@@ -11,6 +11,7 @@
 // from the caller: `arena` (activations that live until backward), `garena` (gradients; never reused inside one
 // backward pass, so the weight gradients running on the lane stream may read them at any time), `scratch` (product
 // rows, reduction workspaces: main stream only), `lane_scratch` (weight-gradient partial slabs: lane stream only).
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -89,9 +90,13 @@ static int g_gemm_bit = 1;
 #define TRYX(bit, expr) TRY(expr)
 #endif
 
-// events for forking the lane stream behind the main stream (one per convolution) and joining it again
+// events for forking the lane stream behind the main stream (one per convolution) and joining it again; one pool per
+// process (one process drives one GPU), grown under a lock: backward passes run on autograd's device threads
 hipEvent_t *event_pool(int n) {
     static std::vector<hipEvent_t> pool;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    if ((int)pool.capacity() < 4096) pool.reserve(4096);   // the returned pointer stays valid while the pool grows
     while ((int)pool.size() < n) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;

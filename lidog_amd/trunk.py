@@ -181,16 +181,23 @@ class _Arenas:
         return t
 
 
+def _structure(model):
+    """identity of every module and parameter of the model: the program holds references to them, so a replaced layer
+    (a new classifier, convert_sync_batchnorm after the first step, a re-assigned parameter) must rebuild it"""
+    return tuple(id(m) for m in model.modules()), tuple(id(p) for p in model.parameters())
+
+
 def program_of(model):
-    prog = model.__dict__.get("_lidog_trunk_program", False)
-    if prog is False:
+    cached = model.__dict__.get("_lidog_trunk_program")
+    sig = _structure(model)
+    if cached is None or cached[0] != sig:
         try:
             prog = Program(model)
         except (_Unsupported, AttributeError):
             prog = None
-        model.__dict__["_lidog_trunk_program"] = prog
-        model.__dict__["_lidog_trunk_arenas"] = _Arenas()
-    return prog
+        cached = model.__dict__["_lidog_trunk_program"] = (sig, prog)
+        model.__dict__.setdefault("_lidog_trunk_arenas", _Arenas())
+    return cached[1]
 
 
 class _Run:

@@ -135,3 +135,20 @@ def test_tables_are_checked(prog):
                                lv.ctypes.data, ext.ctypes.data, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1,
                                None)
     assert rc != 0 and b"rows" in L.lidog_last_error()
+
+
+def test_program_follows_structural_changes_of_the_model():
+    """the program holds references to modules and parameters: replacing one (a new classifier head, SyncBatchNorm
+    conversion after the first step) must rebuild it, an unchanged model must not"""
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd import trunk
+    model = lidog_amd.MinkUNet34BEV(1, 7, 3)
+    p0 = trunk.program_of(model)
+    assert trunk.program_of(model) is p0
+    model.final = ME.MinkowskiConvolution(96, 11, kernel_size=1, bias=True, dimension=3)
+    p1 = trunk.program_of(model)
+    assert p1 is not p0 and p1.ext_shape[trunk.EXT_LOGITS] == (0, 11) and p1.params[-2] is model.final.kernel
+    model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+    p2 = trunk.program_of(model)
+    assert p2 is not p1 and all(type(b) is ME.MinkowskiSyncBatchNorm for b in p2.bns)
