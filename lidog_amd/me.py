@@ -650,7 +650,8 @@ _CENTER_MIN_ROWS = int(os.environ.get("LIDOG_CENTER_MIN_ROWS", "250000"))
 _CENTER_MIN_CH = int(os.environ.get("LIDOG_CENTER_MIN_CH", "96"))
 
 
-_WGRAD_TARGET_BLOCKS = 2048   # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X
+# workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X (LIDOG_WGRAD_BLOCKS: A/B runs)
+_WGRAD_TARGET_BLOCKS = int(os.environ.get("LIDOG_WGRAD_BLOCKS", "2048"))
 
 
 def _wgrad_chunk(P, Cin, Cout):
