@@ -165,6 +165,39 @@ def test_executor_was_taken_and_falls_back_where_it_must():
             torch.testing.assert_close(g1[k], g2[k], rtol=1e-5, atol=1e-7, msg=lambda s: f"{k}: {s}")
 
 
+def test_executor_with_bev_heads_on_every_decoder_level():
+    """decoder_2d_level = all four levels (minkunet_bev.py:128-156): the executor hands back the three inner decoder
+    levels as tensors of their own and takes their gradients; bit-identical to the operator path"""
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd import trunk
+    batch = _batch()
+    res = {}
+    try:
+        for on in (False, True):
+            trunk.set_enabled(on)
+            m = lidog_amd.MinkUNet34BEV(1, 7, 3, decoder_2d_level=["bottle", "block6", "block7", "block8"],
+                                        mapping_bound_2d=5.0).cuda()
+            m.load_state_dict(seeded_state_dict(m, 11))
+            m.train()
+            sem, bev = m(ME.SparseTensor(coordinates=batch["coords_int"], features=batch["source_features0"]),
+                         is_train=True)
+            assert sorted(bev) == ["block6", "block7", "block8", "bottle"]
+            loss = sem.F.square().mean()
+            for k in sorted(bev):
+                loss = loss + bev[k].square().mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            res[on] = ({k: v.detach().clone() for k, v in bev.items()}, float(loss.detach()), _grads(m), _buffers(m))
+    finally:
+        trunk.set_enabled(True)
+    for k in res[True][0]:
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    assert res[True][1] == res[False][1]
+    _assert_same(res[True][2], res[False][2], "gradient")
+    _assert_same(res[True][3], res[False][3], "buffer")
+
+
 def test_maps_outlive_the_sparse_tensors():
     """the caller keeps nothing but the logits: the coordinate manager and its maps must stay alive (and untouched by
     whatever is allocated in between) until the executor's backward has run"""
