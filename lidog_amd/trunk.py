@@ -299,6 +299,8 @@ def _build_tables(prog, x, run):
     for lv in range(N_LEVELS):
         if 2 ** lv not in cm.maps:
             return None
+        if cm.maps[2 ** lv].n == 0:
+            return None
         levels.append(cm.maps[2 ** lv].n)
     for i, (cv, bnm, kind, _, _) in enumerate(prog.convs):
         if kind == KIND_STEM and mobjs[prog.conv_map[i]].nbr is None:
