@@ -6,8 +6,6 @@
 //
 // MFMA 32x32x2 lane maps: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 // D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5) for accumulator register e.
-#include <stdlib.h>
-
 #include "common.h"
 #include "sconv_mfma.h"
 
@@ -250,9 +248,6 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
 int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B, const float *bias,
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
                            int Cin, int Cout, float *T, const int32_t *scatter, hipStream_t st) {
-    static const int use_ws = getenv("LIDOG_GEMM_WS") ? atoi(getenv("LIDOG_GEMM_WS")) : 0;
-    if (use_ws && gather && !scatter && !bias)
-        return lidog_launch_gemm_ws(A, gather, B, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, st);
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)n_tiles, (unsigned)(Cout / (32 * nt)));
 #define LAUNCH(NT_)                                                                                               \
