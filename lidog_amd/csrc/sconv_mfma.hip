@@ -86,19 +86,21 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
 
-    if (tid < MG_TM) {
-        int src = -1, dst = -1;
-        if (tid < rows) {
-            src = gather ? gather[row0 + tid] : (row0 + tid);
-            dst = scatter ? scatter[row0 + tid] : (row0 + tid);
-#ifdef MG_EXP_NOGATHER   // experiment: consecutive (coalesced, cache-resident) source rows instead of the gather
-            src = (row0 + tid) & 0xFFFF;
-#endif
+    // With a scatter index the destination rows go through LDS (every lane of the epilogue needs 16 of them); without
+    // one they are row0 + r, and the gather indices are then fetched by the lanes that use them (8 lanes share an
+    // address: one request) -- no LDS hop and no barrier between the tile descriptor and the first rows.
+    if (scatter) {
+        if (tid < MG_TM) {
+            int src = -1, dst = -1;
+            if (tid < rows) {
+                src = gather ? gather[row0 + tid] : (row0 + tid);
+                dst = scatter[row0 + tid];
+            }
+            s_src[tid] = src;
+            s_dst[tid] = dst;
         }
-        s_src[tid] = src;
-        s_dst[tid] = dst;
+        __syncthreads();
     }
-    __syncthreads();
 
     const float *Bk = B + (size_t)k * Cin * Cout + col0;
     // rb0..rb3 are separate named registers on purpose: as an array (float4 rb[BV]) hipcc keeps the B
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int f = tid + 256 * j;
-        int src = s_src[f >> 3];
+        int r = f >> 3;
+        int src = scatter ? s_src[r] : (r < rows ? (gather ? gather[row0 + r] : row0 + r) : -1);
         a_ok[j] = src >= 0;
         a_row[j] = A + (size_t)(src < 0 ? 0 : src) * Cin + (f & 7) * 4;
     }
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        int dst = s_dst[r];
+        int dst = scatter ? s_dst[r] : (r < rows ? row0 + r : -1);
 #ifdef MG_EXP_NOSTORE    // experiment: no product-row stores (kept live by a never-true condition)
         if (acc[0][e] != 1.2345e30f) dst = -1;
 #endif
