@@ -83,7 +83,6 @@ SIGNATURES = {
     "lidog_allreduce_f64": [_p, _i64, _p, _p],
     "lidog_tiles_host": [_p, _i32, _i32, _i32, _p, _i64],
     "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
-    "lidog_sconv_gemm_dma": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p],
     "lidog_trunk_gemm_timing": [_i32],
     "lidog_trunk_gemm_timing_read": [_p],
     "lidog_trunk_forward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p],
