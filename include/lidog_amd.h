@@ -60,6 +60,20 @@ int lidog_coords_stride(const int32_t *coords_in, int64_t n_in, int32_t new_stri
                         int32_t *vals, int64_t cap, int32_t *parent2child, int32_t *coords_out,
                         int64_t *n_out_dev, int32_t *ws, int32_t *err_flag, void *stream);
 
+/* Occupancy bitmap of a coordinate map over its bounding box (one bit per cell, x fastest, then y, z, batch; x0 / y0 / z0
+ * and every coordinate multiples of `stride`): lidog_kernel_map_bits tests the bit of a neighbour's cell before it
+ * probes the hash table -- 84 % (3^3) to 90 % (5^3) of the neighbours of a LiDAR voxel do not exist, and each of those
+ * probes was a random 64-byte fetch.  lidog_bitmap_words: uint32 words of the bitmap, -1 if it would exceed max_bytes
+ * (the caller then passes bits = NULL: plain probes).  lidog_bitmap_set: bits zeroed by the caller; *err_flag = 2 if a
+ * coordinate lies outside the box.  The neighbour table is the same with or without the bitmap. */
+int64_t lidog_bitmap_words(int32_t nx, int32_t ny, int32_t nz, int32_t nb, int64_t max_bytes);
+int lidog_bitmap_set(const int32_t *coords, int64_t n, int32_t x0, int32_t y0, int32_t z0, int32_t nx, int32_t ny,
+                     int32_t nz, int32_t stride, int32_t nb, uint32_t *bits, int32_t *err_flag, void *stream);
+int lidog_kernel_map_bits(const int32_t *coords_out, int64_t n_out, const uint64_t *in_keys, const int32_t *in_vals,
+                          int64_t in_cap, const int32_t *offsets_host, int32_t K, const uint32_t *bits, int32_t x0,
+                          int32_t y0, int32_t z0, int32_t nx, int32_t ny, int32_t nz, int32_t stride, int32_t nb,
+                          int32_t *nbr, void *stream);
+
 /* Kernel map, neighbour-table form, k-major: nbr[k * n_out + o] = row of the input map holding
  * coordinate out[o] + offsets[k], or -1.  offsets_host is a HOST array [K,3] (x,y,z), K <= 125. */
 int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const uint64_t *in_keys, const int32_t *in_vals,
@@ -67,7 +81,8 @@ int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const uint64_t *i
 
 /* Rule book from the neighbour table (wavefront ballot + prefix-sum compaction): for each k the pairs
  * (pair_in, pair_out) in ascending out-row order, k_off_dev[K+1] segment offsets (device int64),
- * pos_out[k*n_out+o] = pair position or -1, pos_in[k*n_in+i] = pair position or -1.
+ * pos_out[k*n_out+o] = pair position or -1, pos_in[k*n_in+i] = pair position or -1 (both may be NULL when the map
+ * is never walked by row: the 5^3 stem).
  * pair_* need room for n_out*K entries unless the caller knows P.  ws: int32[(blocks+1)*K + K + 2],
  * blocks = ceil(n_out / 1024). */
 int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int32_t K, int64_t *k_off_dev,

@@ -20,6 +20,9 @@ SIGNATURES = {
     "lidog_coords_compact": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p],
     "lidog_coords_stride": [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p],
     "lidog_kernel_map": [_p, _i64, _p, _p, _i64, _p, _i32, _p, _p],
+    "lidog_bitmap_words": [_i32, _i32, _i32, _i32, _i64],
+    "lidog_bitmap_set": [_p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_kernel_map_bits": [_p, _i64, _p, _p, _i64, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_kernel_map_pairs": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
     "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p],
@@ -91,7 +94,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
              "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_sconv_center_reduce_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
-             "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64}
+             "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64, "lidog_bitmap_words": _i64}
 
 _lib = None
 

@@ -307,6 +307,119 @@ __global__ __launch_bounds__(256) void k_kernel_map(const int4 *__restrict__ coo
     nbr[(int64_t)k * n_out + o] = bad ? -1 : lidog_find(keys, vals, mask, key);
 }
 
+// ---- occupancy bitmap of a coordinate map: one bit per cell of its bounding box (x fastest, then y, z, batch).
+// A kernel-map probe first tests the bit of the neighbour's cell: on LiDAR surfaces 84 % of the 3^3 and 90 % of the
+// 5^3 neighbours do not exist, and each of those probes was a random 64-byte fetch from the hash table; the bits of a
+// voxel's neighbourhood sit in a few cache lines that neighbouring voxels share.  Same table afterwards, bit for bit.
+struct BitBox {
+    int32_t x0, y0, z0;   // lowest cell (multiples of the map's tensor stride)
+    int32_t nx, ny, nz;   // cells per axis
+    int32_t stride, nb;   // tensor stride, batch count
+};
+
+__device__ __forceinline__ int64_t bit_index(const BitBox &bx, int b, int x, int y, int z) {
+    // floor division is exact: coordinates of a map are multiples of its stride, and so are x0, y0, z0
+    int ix = (x - bx.x0) / bx.stride, iy = (y - bx.y0) / bx.stride, iz = (z - bx.z0) / bx.stride;
+    if ((unsigned)b >= (unsigned)bx.nb || x < bx.x0 || y < bx.y0 || z < bx.z0 || ix >= bx.nx || iy >= bx.ny || iz >= bx.nz)
+        return -1;
+    return (((int64_t)b * bx.nz + iz) * bx.ny + iy) * bx.nx + ix;
+}
+
+__global__ __launch_bounds__(256) void k_bitmap_set(const int4 *__restrict__ coords, int64_t n, BitBox bx,
+                                                    uint32_t *__restrict__ bits, int32_t *__restrict__ err) {
+    int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    int4 c = coords[o];
+    int64_t i = bit_index(bx, c.x, c.y, c.z, c.w);
+    if (i < 0) {
+        *err = 2;   // a coordinate outside the box it was sized for: the bitmap cannot be trusted
+        return;
+    }
+    atomicOr(&bits[i >> 5], 1u << (i & 31));
+}
+
+// One thread per output voxel, all K offsets: the bits of a voxel's neighbourhood sit in a few words (x is the fastest
+// axis of both the offset list and the bitmap: the 3 or 5 x-neighbours of a (y, z) row share a word, and consecutive
+// voxels share lines), so the bit tests are cache hits and only the existing neighbours (4.3 of 27, ~12 of 125) go to
+// the hash table.  The neighbour table is written k-major as before (coalesced over the voxels of a wave).
+__global__ __launch_bounds__(256) void k_kernel_map_bits(const int4 *__restrict__ coords_out, int64_t n_out,
+                                                         const uint64_t *__restrict__ keys,
+                                                         const int32_t *__restrict__ vals, uint64_t mask, KOffsets offs,
+                                                         int K, BitBox bx, const uint32_t *__restrict__ bits,
+                                                         int32_t *__restrict__ nbr) {
+    __shared__ int32_t s_off[125 * 3];
+    for (int t = threadIdx.x; t < K * 3; t += 256) s_off[t] = offs.d[t];
+    __syncthreads();
+    int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const int4 c = coords_out[o];
+    // five offsets per round (one x-row of a 5^3 kernel): the bit words are requested together, then the existing
+    // neighbours are probed
+    for (int k0 = 0; k0 < K; k0 += 5) {
+        int64_t idx[5];
+        uint32_t word[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = k0 + j < K ? k0 + j : K - 1;
+            idx[j] = bit_index(bx, c.x, c.y + s_off[3 * k], c.z + s_off[3 * k + 1], c.w + s_off[3 * k + 2]);
+            word[j] = bits[idx[j] >= 0 ? idx[j] >> 5 : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = k0 + j;
+            if (k >= K) break;
+            int32_t row = -1;
+            if (idx[j] >= 0 && ((word[j] >> (idx[j] & 31)) & 1u)) {
+                int bad = 0;
+                uint64_t key = lidog_pack(c.x, c.y + s_off[3 * k], c.z + s_off[3 * k + 1], c.w + s_off[3 * k + 2], &bad);
+                row = bad ? -1 : lidog_find(keys, vals, mask, key);
+            }
+            nbr[(int64_t)k * n_out + o] = row;
+        }
+    }
+}
+
+// words (uint32) of the bitmap of a box, or -1 when it would exceed max_bytes
+extern "C" int64_t lidog_bitmap_words(int32_t nx, int32_t ny, int32_t nz, int32_t nb, int64_t max_bytes) {
+    if (nx <= 0 || ny <= 0 || nz <= 0 || nb <= 0) return -1;
+    double cells = (double)nx * ny * nz * nb;
+    if (cells / 8.0 > (double)max_bytes) return -1;
+    return ((int64_t)nx * ny * nz * nb + 31) / 32;
+}
+
+// bits [lidog_bitmap_words] must be zero on entry; err_flag (device int32) is set to 2 if a coordinate lies outside the box
+extern "C" int lidog_bitmap_set(const int32_t *coords, int64_t n, int32_t x0, int32_t y0, int32_t z0, int32_t nx,
+                                int32_t ny, int32_t nz, int32_t stride, int32_t nb, uint32_t *bits, int32_t *err_flag,
+                                void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(stride >= 1 && nx > 0 && ny > 0 && nz > 0 && nb > 0, "bitmap_set: bad box");
+    if (n == 0) return 0;
+    BitBox bx{x0, y0, z0, nx, ny, nz, stride, nb};
+    k_bitmap_set<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>((const int4 *)coords, n, bx, bits, err_flag);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// lidog_kernel_map with the occupancy bitmap of the INPUT map in front of the hash probes (bits == NULL: plain probes)
+extern "C" int lidog_kernel_map_bits(const int32_t *coords_out, int64_t n_out, const uint64_t *in_keys,
+                                     const int32_t *in_vals, int64_t in_cap, const int32_t *offsets_host, int32_t K,
+                                     const uint32_t *bits, int32_t x0, int32_t y0, int32_t z0, int32_t nx, int32_t ny,
+                                     int32_t nz, int32_t stride, int32_t nb, int32_t *nbr, void *stream) {
+    if (bits == nullptr)
+        return lidog_kernel_map(coords_out, n_out, in_keys, in_vals, in_cap, offsets_host, K, nbr, stream);
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(K >= 1 && K <= 125, "kernel_map: K=%d out of range [1,125]", K);
+    LIDOG_REQUIRE(stride >= 1 && nx > 0 && ny > 0 && nz > 0 && nb > 0, "kernel_map_bits: bad box");
+    if (n_out == 0) return 0;
+    KOffsets offs;
+    for (int i = 0; i < K * 3; ++i) offs.d[i] = offsets_host[i];
+    BitBox bx{x0, y0, z0, nx, ny, nz, stride, nb};
+    k_kernel_map_bits<<<(unsigned)cdiv64(n_out, 256), 256, 0, st>>>((const int4 *)coords_out, n_out, in_keys, in_vals,
+                                                                    (uint64_t)(in_cap - 1), offs, K, bx, bits, nbr);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const uint64_t *in_keys,
                                 const int32_t *in_vals, int64_t in_cap, const int32_t *offsets_host, int32_t K,
                                 int32_t *nbr, void *stream) {
@@ -399,9 +512,9 @@ __global__ __launch_bounds__(256) void k_pairs_emit(const int32_t *__restrict__ 
                 p = (int32_t)(base + rank);
                 pair_in[p] = nb_[j];
                 pair_out[p] = (int32_t)o;
-                pos_in[(int64_t)k * n_in + nb_[j]] = p;
+                if (pos_in) pos_in[(int64_t)k * n_in + nb_[j]] = p;
             }
-            pos_out[(int64_t)k * n_out + o] = p;
+            if (pos_out) pos_out[(int64_t)k * n_out + o] = p;
         }
     }
 }
@@ -412,7 +525,8 @@ extern "C" int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(K >= 1 && K <= 125, "kernel_map_pairs: K=%d out of range [1,125]", K);
     LIDOG_REQUIRE(n_out * (int64_t)K < 0x7fffffff, "kernel_map_pairs: pair positions overflow int32");
-    LIDOG_CHECK_HIP(hipMemsetAsync(pos_in, 0xff, sizeof(int32_t) * n_in * K, st));
+    // pos_out / pos_in == NULL: the caller never walks this map by row (the 5^3 stem: 2 x 125 n ints not written)
+    if (pos_in) LIDOG_CHECK_HIP(hipMemsetAsync(pos_in, 0xff, sizeof(int32_t) * n_in * K, st));
     if (n_out == 0) {
         LIDOG_CHECK_HIP(hipMemsetAsync(k_off_dev, 0, sizeof(int64_t) * (K + 1), st));
         return 0;

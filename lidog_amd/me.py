@@ -90,10 +90,11 @@ def _center_of(key):
 
 
 class _CoordMap:
-    __slots__ = ("coords", "keys", "vals", "cap", "n")
+    __slots__ = ("coords", "keys", "vals", "cap", "n", "bits", "box")
 
     def __init__(self, coords, keys, vals, cap):
         self.coords, self.keys, self.vals, self.cap, self.n = coords, keys, vals, cap, coords.shape[0]
+        self.bits = self.box = None    # occupancy bitmap over the bounding box (CoordinateManager._bitmap)
 
 
 class KernelMap:
@@ -103,13 +104,32 @@ class KernelMap:
         self.K, self.n_in, self.n_out = K, n_in, n_out
         self.k_off, self.k_off_host = k_off, k_off_host
         self.P = int(k_off_host[-1])
-        self.pair_in, self.pair_out, self.pos_out, self.pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
+        self.pair_in, self.pair_out, self._pos_out, self._pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
         self.tiles, self.n_tiles = tiles if tiles is not None else _tiles(k_off_host, pair_in.device)
         self._rows = {}
         # centre offset of a stride-1 odd kernel: its segment of the rule book is the identity map (every voxel pairs
         # with itself), which lets the reduction pass compute its products itself (csrc/sconv_center.hip)
         self.center = -1
         self._tiles_nc = None
+
+    def _pos_table(self, side):
+        """[K, n] pair position of (offset, row) or -1.  Written with the rule book for K <= 27; a 5^3 map (the Cin = 1
+        stem never walks it by row) gets it on first request, from the pair lists (not on the training path)."""
+        name = "_pos_" + side
+        t = getattr(self, name)
+        if t is None:
+            n = self.n_out if side == "out" else self.n_in
+            rows = (self.pair_out if side == "out" else self.pair_in).long()
+            dev = rows.device
+            t = torch.full((self.K, n), -1, dtype=torch.int32, device=dev)
+            counts = torch.tensor(np.diff(np.asarray(self.k_off_host, dtype=np.int64)), device=dev)
+            ks = torch.repeat_interleave(torch.arange(self.K, device=dev), counts)
+            t[ks, rows] = torch.arange(self.P, dtype=torch.int32, device=dev)
+            setattr(self, name, t)
+        return t
+
+    pos_out = property(lambda self: self._pos_table("out"))
+    pos_in = property(lambda self: self._pos_table("in"))
 
     def set_center(self, k, tiles_nc=None):
         if int(self.k_off_host[k + 1]) - int(self.k_off_host[k]) == self.n_out == self.n_in:
@@ -153,6 +173,7 @@ class _IdentityMap:
 
 
 _SIDE_STREAMS = {}
+_EXP_KEPT = {}
 
 
 def _side_stream(device):
@@ -277,7 +298,16 @@ class CoordinateManager:
             cm = cls(dev)
             cm.uniq, _ = cm.insert(coordinates)
             cm._own(coordinates)
+            keep = os.environ.get("LIDOG_EXP_KEEP_MAPS", "")   # timing experiment: these kernel maps are built once per batch
+            if keep:
+                cache = _EXP_KEPT.setdefault(id(coordinates), {})
+                for key, m in cache.items():
+                    cm.kmaps[key] = m
             cm.prefetch(trace)
+            if keep:
+                for key in list(cm.kmaps):
+                    if (keep == "stem" and key[2] == 5) or (keep == "k3" and key[2] == 3) or keep == "all":
+                        cache[key] = cm.kmaps[key]
             cm._ready = torch.cuda.Event()
             cm._ready.record(side)
         return cm
@@ -378,7 +408,13 @@ class CoordinateManager:
         n_unique = torch.zeros(1, dtype=torch.int64, device=self.device)
         call("lidog_coords_insert", ptr(coords), n, ptr(keys), ptr(vals), cap, ptr(first), ptr(n_unique),
              ptr(self.err))
-        stats = torch.stack([n_unique[0], self.err[0].long(), coords[:, 0].max().long() if n else n_unique[0]]).tolist()
+        if n:   # bounding box of the voxels (for the occupancy bitmaps), in the same read-back as the counts
+            lo, hi = coords[:, 1:].amin(0).long(), coords[:, 1:].amax(0).long()
+            stats = torch.cat([torch.stack([n_unique[0], self.err[0].long(), coords[:, 0].max().long()]), lo, hi]).tolist()
+            self.bounds = (tuple(stats[3:6]), tuple(stats[6:9]))
+        else:
+            stats = torch.stack([n_unique[0], self.err[0].long(), n_unique[0]]).tolist()
+            self.bounds = None
         if stats[1] != 0:
             self._check()
         self.batch_size = int(stats[2]) + 1 if n else 0
@@ -414,6 +450,27 @@ class CoordinateManager:
         self.maps[s_out] = _CoordMap(out[:m], keys, vals, cap)  # out[:m] stays contiguous (leading rows)
         return self.maps[s_out]
 
+    def _bitmap(self, s):
+        """occupancy bitmap of the coordinate map of tensor stride s over the batch's bounding box (bits, box) or
+        (None, None): no bounds known, or the box would take more than _BITMAP_MAX_BYTES"""
+        cmap = self.maps[s]
+        if cmap.box is not None:
+            return cmap.bits, cmap.box
+        cmap.box = ()
+        if not _BITMAPS or getattr(self, "bounds", None) is None or cmap.n == 0:
+            return None, ()
+        lo, hi = self.bounds
+        x0 = [(int(v) // s) * s for v in lo]            # python floor division: toward -inf, as the strided maps do
+        nn = [(int(h) // s) * s // s - a // s + 1 for h, a in zip(hi, x0)]
+        words = _lib.load().lidog_bitmap_words(nn[0], nn[1], nn[2], self.batch_size, _BITMAP_MAX_BYTES)
+        if words < 0:
+            return None, ()
+        bits = self._own(torch.zeros(words, dtype=torch.int32, device=self.device))
+        box = (x0[0], x0[1], x0[2], nn[0], nn[1], nn[2], s, self.batch_size)
+        call("lidog_bitmap_set", ptr(cmap.coords), cmap.n, *box, ptr(bits), ptr(self.err))
+        cmap.bits, cmap.box = bits, box
+        return bits, box
+
     def kernel_map(self, s_in, s_out, kernel_size, dilation=1):
         key = (s_in, s_out, kernel_size, dilation)
         if key in self.kmaps:
@@ -434,18 +491,26 @@ class CoordinateManager:
         K = offs.shape[0]
         n_in, n_out = cin.n, cout.n
         nbr = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
-        call("lidog_kernel_map", ptr(cout.coords), n_out, ptr(cin.keys), ptr(cin.vals), cin.cap,
-             offs.ctypes.data, K, ptr(nbr))
+        bits, box = self._bitmap(s_in)
+        if bits is not None:
+            call("lidog_kernel_map_bits", ptr(cout.coords), n_out, ptr(cin.keys), ptr(cin.vals), cin.cap,
+                 offs.ctypes.data, K, ptr(bits), *box, ptr(nbr))
+        else:
+            call("lidog_kernel_map", ptr(cout.coords), n_out, ptr(cin.keys), ptr(cin.vals), cin.cap,
+                 offs.ctypes.data, K, ptr(nbr))
         k_off = torch.empty(K + 1, dtype=torch.int64, device=self.device)
         pair_in = torch.empty(n_out * K, dtype=torch.int32, device=self.device)
         pair_out = torch.empty(n_out * K, dtype=torch.int32, device=self.device)
-        pos_out = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
-        pos_in = torch.empty((K, n_in), dtype=torch.int32, device=self.device)
+        # position tables: what the per-row lists are built from (3^3 and 2^3 maps) and what the dense-table reduction
+        # of odd channel counts walks; a 5^3 map (the stem: straight from the neighbour table) never needs them
+        by_row = K <= 27
+        pos_out = torch.empty((K, n_out), dtype=torch.int32, device=self.device) if by_row else None
+        pos_in = torch.empty((K, n_in), dtype=torch.int32, device=self.device) if by_row else None
         nbp = (n_out + 1023) // 1024
         ws = torch.empty((nbp + 1) * K + K + 2, dtype=torch.int32, device=self.device)
         call("lidog_kernel_map_pairs", ptr(nbr), n_out, n_in, K, ptr(k_off), ptr(pair_in), ptr(pair_out),
              ptr(pos_out), ptr(pos_in), ptr(ws))
-        self._own(nbr, k_off, pair_in, pair_out, pos_out, pos_in)
+        self._own(*[t for t in (nbr, k_off, pair_in, pair_out, pos_out, pos_in) if t is not None])
         return (K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr)
 
     def _kernel_map_finish(self, pd, k_off_host, tiles, key=None, tiles_nc=None):
@@ -646,6 +711,9 @@ def _use_center(m, Cin, Cout):
 # co-running on the second stream) the difference vanishes: 50.54 vs 50.57 ms per step, twice.  OFF by default;
 # LIDOG_CENTER_FUSED=1 turns it on for the layers above the two thresholds (results are bit-identical either way).
 _CENTER_FUSED = os.environ.get("LIDOG_CENTER_FUSED", "0") == "1"
+# occupancy bitmaps in front of the kernel maps' hash probes (CoordinateManager._bitmap); 0 = plain probes
+_BITMAPS = os.environ.get("LIDOG_MAP_BITMAPS", "1") != "0"
+_BITMAP_MAX_BYTES = int(os.environ.get("LIDOG_MAP_BITMAP_MAX_MB", "1024")) << 20
 _CENTER_MIN_ROWS = int(os.environ.get("LIDOG_CENTER_MIN_ROWS", "250000"))
 _CENTER_MIN_CH = int(os.environ.get("LIDOG_CENTER_MIN_CH", "96"))
 
