@@ -353,21 +353,24 @@ __global__ __launch_bounds__(256) void k_kernel_map_bits(const int4 *__restrict_
     int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= n_out) return;
     const int4 c = coords_out[o];
-    // five offsets per round (one x-row of a 5^3 kernel): the bit words are requested together, then the existing
-    // neighbours are probed
-    for (int k0 = 0; k0 < K; k0 += 5) {
+    // blockIdx.y takes one slab of the offsets (a z-plane of a 5^3 or 3^3 kernel): more threads in flight for what is a
+    // chain of dependent cache hits and probes per thread.  Five offsets per round (one x-row of a 5^3 kernel): the bit
+    // words are requested together, then the existing neighbours are probed
+    const int per = (K + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k_begin = (int)blockIdx.y * per, k_end = k_begin + per < K ? k_begin + per : K;
+    for (int k0 = k_begin; k0 < k_end; k0 += 5) {
         int64_t idx[5];
         uint32_t word[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int k = k0 + j < K ? k0 + j : K - 1;
+            const int k = k0 + j < k_end ? k0 + j : k_end - 1;
             idx[j] = bit_index(bx, c.x, c.y + s_off[3 * k], c.z + s_off[3 * k + 1], c.w + s_off[3 * k + 2]);
             word[j] = bits[idx[j] >= 0 ? idx[j] >> 5 : 0];
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int k = k0 + j;
-            if (k >= K) break;
+            if (k >= k_end) break;
             int32_t row = -1;
             if (idx[j] >= 0 && ((word[j] >> (idx[j] & 31)) & 1u)) {
                 int bad = 0;
@@ -414,8 +417,10 @@ extern "C" int lidog_kernel_map_bits(const int32_t *coords_out, int64_t n_out, c
     KOffsets offs;
     for (int i = 0; i < K * 3; ++i) offs.d[i] = offsets_host[i];
     BitBox bx{x0, y0, z0, nx, ny, nz, stride, nb};
-    k_kernel_map_bits<<<(unsigned)cdiv64(n_out, 256), 256, 0, st>>>((const int4 *)coords_out, n_out, in_keys, in_vals,
-                                                                    (uint64_t)(in_cap - 1), offs, K, bx, bits, nbr);
+    int slabs = (K % 25 == 0) ? K / 25 : (K % 9 == 0) ? K / 9 : 1;     // z-planes of a 5^3 / 3^3 kernel
+    dim3 grid((unsigned)cdiv64(n_out, 256), (unsigned)slabs);
+    k_kernel_map_bits<<<grid, 256, 0, st>>>((const int4 *)coords_out, n_out, in_keys, in_vals, (uint64_t)(in_cap - 1),
+                                            offs, K, bx, bits, nbr);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
