@@ -343,7 +343,10 @@ class CoordinateManager:
             if s_out != s_in:
                 self.stride(s_in, s_out)
             pending.append((key, self._kernel_map_launch(key)))
-        hosts = torch.cat([pd[3] for _, pd in pending]).tolist() if pending else []
+        # the error word rides along: k_bitmap_set flags a coordinate outside the box its bitmap was sized for
+        hosts = torch.cat([pd[3] for _, pd in pending] + [self.err.long()]).tolist() if pending else []
+        if pending and hosts[-1] != 0:
+            self._check(int(hosts[-1]))
         arena, todo, off = _Arena(), [], 0
         for key, pd in pending:
             K = pd[0]
@@ -393,8 +396,12 @@ class CoordinateManager:
             m = self.identity[self.maps[key[1]].n] if key[0] == "identity" else self.kmaps[key]
             m.__dict__.setdefault("_wgrad_items", {})[chunk] = (views[islot], total, views[oslot])
 
-    def _check(self):
-        if int(self.err.item()) != 0:
+    def _check(self, code=None):
+        code = int(self.err.item()) if code is None else code
+        if code == 2:
+            raise RuntimeError("occupancy bitmap: a coordinate lies outside the bounding box the bitmap was sized for "
+                               "(kernel maps built through it would drop neighbours); LIDOG_MAP_BITMAPS=0 disables them")
+        if code != 0:
             raise ValueError("coordinates out of the supported range: |x|,|y|,|z| <= 65535, 0 <= batch <= 4095")
 
     def insert(self, coords):
@@ -479,7 +486,9 @@ class CoordinateManager:
         if s_out != s_in:
             self.stride(s_in, s_out)
         pd = self._kernel_map_launch(key)
-        k_off_host = pd[3].tolist()  # one synchronisation per kernel map on this (lazy) path
+        k_off_host = torch.cat([pd[3], self.err.long()]).tolist()  # one synchronisation per kernel map on this (lazy) path
+        if k_off_host.pop() != 0:
+            self._check()
         self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, None, key)
         return self.kmaps[key]
 

@@ -1,0 +1,187 @@
+"""Kernel maps and one convolution layer at BASELINE size against the CPU oracle, bit for bit.
+
+The bench workload (configs[1], 88 k voxels per scan) builds the maps of every coordinate map of >= 40 000 rows through
+`k_kernel_map_bits` (occupancy bitmap in front of the hash probes, csrc/coords.hip); the operator tests of
+tests/test_gpu_ops.py use <= 9 000 rows and therefore the plain-probe kernel.  Here the SAME maps the bench builds --
+5^3 at stride 1, 3^3 at strides 1/2/4/8/16, 2^3 between consecutive strides -- are compared with `orc_kernel_map`
+(oracle/me_oracle.c) and with the plain-probe kernel on the same tables: neighbour tables, pair lists (order included)
+and offsets.  Reference call sites: utils/models/minkunet_bev.py:57-123 (every MinkowskiConvolution of the network)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KEYS = [(1, 1, 5), (1, 1, 3), (1, 2, 2), (2, 2, 3), (2, 4, 2), (4, 4, 3), (4, 8, 2), (8, 8, 3), (8, 16, 2), (16, 16, 3)]
+
+
+def _oracle_and_gpu(coords):
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    coords = coords.cpu().contiguous()
+    so = OME.SparseTensor(coordinates=coords, features=torch.ones(coords.shape[0], 1))
+    sg = ME.SparseTensor(coordinates=coords.cuda(), features=torch.ones(coords.shape[0], 1, device="cuda"))
+    return so.coordinate_manager, sg.coordinate_manager
+
+
+def _assert_same_map(ocm, gcm, key, plain=None):
+    s_in, s_out, ks = key
+    k_off, pin, pout, nbr = ocm.kernel_map(s_in, s_out, ks)
+    km = gcm.kernel_map(s_in, s_out, ks)
+    assert km.k_off_host == k_off.tolist(), f"{key}: pairs per offset differ"
+    assert torch.equal(nbr.t().contiguous(), km.nbr.cpu()), f"{key}: neighbour table differs from the oracle's"
+    assert torch.equal(pin, km.pair_in.cpu()) and torch.equal(pout, km.pair_out.cpu()), f"{key}: pair lists differ"
+    if plain is not None:
+        kp = plain.kernel_map(s_in, s_out, ks)
+        assert torch.equal(kp.nbr, km.nbr) and torch.equal(kp.pair_in, km.pair_in) and \
+            torch.equal(kp.pair_out, km.pair_out) and kp.k_off_host == km.k_off_host, f"{key}: bitmap != plain probes"
+    return km
+
+
+def _strides_equal(ocm, gcm):
+    prev = 1
+    for s in (2, 4, 8, 16):
+        co = ocm.stride(prev, s)
+        cg = gcm.stride(prev, s).coords
+        assert torch.equal(co, cg.cpu()), f"stride {s}: voxel rows differ from the oracle's"
+        prev = s
+
+
+@pytest.mark.parametrize("seeds", [(0, 1), (2, 3, 4, 5)], ids=["bs2", "bs4"])
+def test_bench_size_maps_equal_the_oracle_and_the_plain_probe_kernel(seeds, monkeypatch):
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    coords = synth.make_batch(seeds, "kitti120k", "cpu")["coords_int"]
+    assert coords.shape[0] >= 170000
+    assert int(coords[:, 1:].min()) < 0                       # LiDAR coordinates are negative on half the scene
+    ocm, gcm = _oracle_and_gpu(coords)
+    monkeypatch.setattr(ME, "_BITMAPS", False)
+    plain = ME.SparseTensor(coordinates=coords.cuda(), features=torch.ones(coords.shape[0], 1, device="cuda")).coordinate_manager
+    monkeypatch.setattr(ME, "_BITMAPS", True)
+    _strides_equal(ocm, gcm)
+    _strides_equal(ocm, plain)
+    for key in KEYS:
+        _assert_same_map(ocm, gcm, key, plain)
+    # the bitmap kernel really was the one that built the big maps (and the plain one the reference manager's)
+    assert gcm.maps[1].bits is not None and gcm.maps[2].bits is not None
+    assert all(getattr(m, "bits", None) is None for m in plain.maps.values())
+    if len(seeds) == 4:
+        assert gcm.maps[4].n >= ME._BITMAP_MIN_ROWS and gcm.maps[4].bits is not None
+
+
+def test_prepared_maps_at_bench_size_equal_the_oracle():
+    """the path the bench takes: CoordinateManager.prepare builds all ten maps on the side stream from a trace"""
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    coords = synth.make_batch((0, 1), "kitti120k", "cpu")["coords_int"]
+    import oracle.me_cpu as OME
+    ocm = OME.SparseTensor(coordinates=coords, features=torch.ones(coords.shape[0], 1)).coordinate_manager
+    trace = [((s_in, s_out, ks, 1), 32, 32) for s_in, s_out, ks in KEYS]
+    gcm = ME.CoordinateManager.prepare(coords.cuda(), trace)
+    gcm.handover()
+    torch.cuda.synchronize()
+    _strides_equal(ocm, gcm)
+    for key in KEYS:
+        assert (key + (1,)) in gcm.kmaps, f"{key} was not prepared"
+        _assert_same_map(ocm, gcm, key)
+    assert gcm.maps[1].bits is not None
+
+
+@pytest.mark.parametrize("shift", [(-3, 5, -7), (1001, -999, 13)])
+def test_bitmap_maps_with_negative_and_unaligned_boxes(shift, monkeypatch):
+    """a box whose low corner is not a multiple of the coarser strides, all-negative and mixed-sign coordinates"""
+    import lidog_amd.me as ME
+    monkeypatch.setattr(ME, "_BITMAP_MIN_ROWS", 1000)
+    g = torch.Generator().manual_seed(11)
+    n = 60000
+    c = torch.randint(-70, 63, (n, 3), generator=g, dtype=torch.int32)
+    c[:, 2] = torch.randint(-9, 6, (n,), generator=g, dtype=torch.int32)
+    c = c + torch.tensor(shift, dtype=torch.int32)
+    b = torch.randint(0, 3, (n, 1), generator=g, dtype=torch.int32)
+    coords = torch.unique(torch.cat([b, c], 1), dim=0)
+    coords = coords[torch.randperm(coords.shape[0], generator=g)].contiguous()
+    ocm, gcm = _oracle_and_gpu(coords)
+    monkeypatch.setattr(ME, "_BITMAPS", False)
+    plain = ME.SparseTensor(coordinates=coords.cuda(), features=torch.ones(coords.shape[0], 1, device="cuda")).coordinate_manager
+    monkeypatch.setattr(ME, "_BITMAPS", True)
+    _strides_equal(ocm, gcm)
+    for key in KEYS:
+        _assert_same_map(ocm, gcm, key, plain)
+    assert all(gcm.maps[s].bits is not None for s in (1, 2, 4, 8) if gcm.maps[s].n >= 1000)
+
+
+def test_bitmap_size_limit_falls_back_to_plain_probes(monkeypatch):
+    """LIDOG_MAP_BITMAP_MAX_MB: a box too large for the limit (the high-resolution config at a small limit) takes the
+    plain kernel, same tables"""
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    coords = synth.make_batch((0,), "kitti120k", "cpu")["coords_int"]
+    monkeypatch.setattr(ME, "_BITMAP_MAX_BYTES", 1 << 20)     # 1 MB: stride 1 and 2 exceed it, stride 4 fits
+    monkeypatch.setattr(ME, "_BITMAP_MIN_ROWS", 1000)
+    ocm, gcm = _oracle_and_gpu(coords)
+    _strides_equal(ocm, gcm)
+    for key in [(1, 1, 3), (1, 2, 2), (2, 2, 3), (2, 4, 2), (4, 4, 3), (8, 8, 3)]:
+        _assert_same_map(ocm, gcm, key)
+    assert gcm.maps[1].bits is None and gcm.maps[1].box == ()
+    assert gcm.maps[8].bits is not None
+
+
+def test_bitmap_error_word_reaches_the_host(monkeypatch):
+    """a box that does not cover the coordinates (here: forged bounds) must raise, not drop neighbours silently"""
+    import lidog_amd.me as ME
+    monkeypatch.setattr(ME, "_BITMAP_MIN_ROWS", 1000)
+    g = torch.Generator().manual_seed(5)
+    c = torch.unique(torch.cat([torch.zeros(20000, 1, dtype=torch.int32),
+                                torch.randint(-40, 40, (20000, 3), generator=g, dtype=torch.int32)], 1), dim=0)
+    cm = ME.SparseTensor(coordinates=c.cuda(), features=torch.ones(c.shape[0], 1, device="cuda")).coordinate_manager
+    lo, hi = cm.bounds
+    cm.bounds = ((lo[0] + 8, lo[1], lo[2]), hi)               # the box misses the lowest x cells
+    with pytest.raises(RuntimeError, match="occupancy bitmap"):
+        cm.kernel_map(1, 1, 3)
+
+
+def test_highres_maps_equal_the_oracle():
+    """configs[4] (461 k voxels, 0.02 m): stride-1 and stride-2 3^3 maps + the stem's 5^3 map against the oracle"""
+    from lidog_amd import synth
+    coords = synth.make_batch((0,), "highres524k", "cpu")["coords_int"]
+    assert coords.shape[0] > 400000
+    ocm, gcm = _oracle_and_gpu(coords)
+    _strides_equal(ocm, gcm)
+    for key in [(1, 1, 5), (1, 1, 3), (1, 2, 2), (2, 2, 3), (2, 4, 2), (4, 4, 3)]:
+        _assert_same_map(ocm, gcm, key)
+
+
+@pytest.mark.parametrize("core", [1, 0], ids=["mfma_f32", "vector_fma"])
+def test_conv_layer_at_one_bench_scan_is_bit_exact(core):
+    """block8's 96 -> 96 3^3 stride-1 convolution on scan 0 (88 117 voxels): forward and data gradient bit-exact against
+    the oracle's fmaf chains (ascending input channel, ascending offset), weight gradient within 2e-5 of its scale"""
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    from lidog_amd import _lib, synth
+    L = _lib.load()
+    assert L.lidog_set_sparse_core(core) == 0
+    try:
+        OME.set_mode("exact")
+        coords = synth.make_batch((0,), "kitti120k", "cpu")["coords_int"]
+        n = coords.shape[0]
+        assert n == synth.BASELINE_COUNTS["kitti120k"][0]
+        ocm, gcm = _oracle_and_gpu(coords)
+        g = torch.Generator().manual_seed(96)
+        x = torch.randn(n, 96, generator=g)
+        gy = torch.randn(n, 96, generator=g)
+        co = OME.MinkowskiConvolution(96, 96, kernel_size=3, stride=1, bias=False, dimension=3)
+        cg = ME.MinkowskiConvolution(96, 96, kernel_size=3, stride=1, bias=False, dimension=3).cuda()
+        cg.load_state_dict(co.state_dict())
+        xo = x.clone().requires_grad_(True)
+        xg = x.clone().cuda().requires_grad_(True)
+        yo = co(OME.SparseTensor(xo, coordinate_manager=ocm, coordinate_map_key=1))
+        yg = cg(ME.SparseTensor(xg, coordinate_manager=gcm, coordinate_map_key=1))
+        assert gcm.maps[1].bits is not None                   # the map came from the bitmap kernel
+        assert torch.equal(yo.F.detach(), yg.F.detach().cpu()), (yo.F.detach() - yg.F.detach().cpu()).abs().max()
+        yo.F.backward(gy)
+        yg.F.backward(gy.cuda())
+        assert torch.equal(xo.grad, xg.grad.cpu()), (xo.grad - xg.grad.cpu()).abs().max()
+        scale = co.kernel.grad.abs().max().item()
+        assert (co.kernel.grad - cg.kernel.grad.cpu()).abs().max().item() <= 2e-5 * scale
+    finally:
+        L.lidog_set_sparse_core(1)
