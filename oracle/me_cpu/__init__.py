@@ -171,8 +171,14 @@ class _SparseConvFn(torch.autograd.Function):
         K, Cin, Cout = W.shape
         x = x.contiguous()
         W = W.contiguous()
-        out = torch.zeros((n_out, Cout), dtype=torch.float32)
-        if _MODE == "exact":
+        out = torch.zeros((n_out, Cout), dtype=x.dtype)
+        if x.dtype != torch.float32:
+            # float64 ground truth for the gradient tests (tests/golden/make_golden.py g5): same algorithm in torch ops
+            for k in range(K):
+                a, b = int(k_off[k]), int(k_off[k + 1])
+                if b > a:
+                    out.index_add_(0, pout[a:b].long(), x[pin[a:b].long()] @ W[k])
+        elif _MODE == "exact":
             lib().orc_conv_fwd(_ptr(x), _ptr(W), _ptr(k_off), _ptr(pin), _ptr(pout), K, Cin, Cout, _ptr(out))
         else:  # ME's CPU algorithm: per offset gather rows -> BLAS GEMM -> scatter-add rows (OpenMP helpers)
             for k in range(K):
@@ -189,7 +195,14 @@ class _SparseConvFn(torch.autograd.Function):
         gout = gout.contiguous()
         gin = torch.zeros_like(x)
         gW = torch.zeros_like(W)
-        if _MODE == "exact":
+        if x.dtype != torch.float32:
+            for k in range(K):
+                a, b = int(k_off[k]), int(k_off[k + 1])
+                if b > a:
+                    g = gout[pout[a:b].long()]
+                    gin.index_add_(0, pin[a:b].long(), g @ W[k].t())
+                    gW[k] = x[pin[a:b].long()].t() @ g
+        elif _MODE == "exact":
             lib().orc_conv_bwd_data(_ptr(gout), _ptr(W), _ptr(k_off), _ptr(pin), _ptr(pout), K, Cin, Cout, _ptr(gin))
             lib().orc_conv_bwd_weight(_ptr(x), _ptr(gout), _ptr(k_off), _ptr(pin), _ptr(pout), K, Cin, Cout, _ptr(gW))
         else:

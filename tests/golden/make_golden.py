@@ -14,6 +14,8 @@ What executes reference code here:
                                at that boundary, see oracle/me_oracle.c)
   G6  MinkUNet34            <- utils/models/minkunet.py class, same arrangement
   G7  BEV label images      <- PC2ImgConverter.getBEVImageNew (utils/datasets/semantickitti_bev.py:433-464)
+  G8  float64 ground truth  <- the G5 / G6 runs repeated with model.double() on the oracle's float64 path
+                               (training-mode BatchNorm): gradient vectors + how far the float32 golden run is from them
 """
 import hashlib
 import os
@@ -303,9 +305,95 @@ def g7_bev_labels():
     np.savez_compressed(os.path.join(HERE, "g7_bev_labels.npz"), **out)
 
 
+G8_VECTORS = ["conv1p1s2.kernel", "bn1.bn.weight", "block1.0.conv1.kernel", "block1.1.norm2.bn.weight",
+              "block1.1.norm2.bn.bias", "conv2p2s2.kernel", "block2.0.downsample.0.kernel", "block2.0.norm1.bn.weight",
+              "conv3p4s2.kernel", "block3.0.norm1.bn.bias", "block3.0.downsample.0.kernel", "conv4p8s2.kernel",
+              "block4.0.downsample.0.kernel", "block4.5.norm2.bn.weight", "bntr4.bn.weight", "bntr4.bn.bias",
+              "block5.0.downsample.0.kernel", "convtr6p4s2.kernel", "block7.0.downsample.0.kernel", "convtr7p2s2.kernel",
+              "block8.0.norm1.bn.weight", "block8.1.norm2.bn.weight", "block8.1.norm2.bn.bias", "final.kernel"]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def g8_float64():
+    """Ground truth for the training-mode gradient checks: the reference's classes on the oracle in float64
+    (convolutions, BatchNorm, BEV head, losses all in double).  Stored per vector: the float64 gradient (as float32)
+    and the relative L2 distance of the float32 golden run (same code, float32, one thread) from it -- the yardstick
+    the HIP path is held to (tests/test_gpu_model.py)."""
+    out = {}
+
+    def run_bev(dt):
+        C = small_batch((0, 1))
+        N = C.shape[0]
+        g = torch.Generator().manual_seed(23)
+        labels = torch.randint(-1, 7, (N,), generator=g)
+        bev_labels = torch.randint(-1, 7, (2, 17, 17), generator=g)
+        model = RefBEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"],
+                       mapping_bound_2d=5.0)
+        model.load_state_dict(seeded_state_dict(model, seed=5))
+        if dt == torch.float64:
+            model.double()
+            zeros = torch.zeros
+
+            def s2s(x, **kw):   # the reference method allocates its image with torch.zeros (float32): keep float64
+                torch.zeros = lambda *a, **k: zeros(*a, **({**k, "dtype": torch.float64} if "dtype" not in k else k))
+                try:
+                    return RefBEV.sparse2super(model, x, **kw)
+                finally:
+                    torch.zeros = zeros
+            model.sparse2super = s2s
+        model.train()
+        sem, bev = model(ME.SparseTensor(coordinates=C, features=torch.ones((N, 1), dtype=dt)), is_train=True)
+        loss = 0.5 * SoftDICELoss(ignore_label=-1)(sem.F, labels).cpu() + \
+            0.5 * DICELoss(ignore_label=-1)(bev["block8"].view(-1, 7).cpu(), bev_labels.view(-1).cpu())
+        loss.backward()
+        return model, sem, bev, loss
+
+    def run_unet(dt):
+        C = small_batch((7,), n_points=2000)
+        N = C.shape[0]
+        g = torch.Generator().manual_seed(29)
+        labels = torch.randint(-1, 7, (N,), generator=g)
+        model = RefUNet(in_channels=1, out_channels=7, D=3)
+        model.load_state_dict(seeded_state_dict(model, seed=7))
+        if dt == torch.float64:
+            model.double()
+        model.train()
+        sem = model(ME.SparseTensor(coordinates=C, features=torch.ones((N, 1), dtype=dt)), is_seg=True)
+        loss = SoftDICELoss(ignore_label=-1)(sem.F, labels)
+        loss.backward()
+        return model, sem, None, loss
+
+    for tag, run, names in (("g5", run_bev, G8_VECTORS + ["encoders2d.block8.out_conv.conv.weight"]),
+                            ("g6", run_unet, G8_VECTORS)):
+        m64, sem64, bev64, loss64 = run(torch.float64)
+        m32, sem32, bev32, loss32 = run(torch.float32)
+        p64, p32 = dict(m64.named_parameters()), dict(m32.named_parameters())
+        out[f"{tag}/logits64"] = sem64.F.detach().numpy().astype(np.float32)
+        out[f"{tag}/logits_err32"] = np.float64((sem64.F.detach() - sem32.F.detach().double()).abs().max())
+        out[f"{tag}/loss64"] = np.float64(loss64.detach())
+        if bev64 is not None:
+            out[f"{tag}/bev_logits64"] = bev64["block8"].detach().numpy().astype(np.float32)
+        errs = []
+        for n in names:
+            out[f"{tag}/grad64/{n}"] = p64[n].grad.numpy().astype(np.float32)
+            out[f"{tag}/err32/{n}"] = np.float64(_rel(p32[n].grad.numpy(), p64[n].grad.numpy()))
+            errs.append(float(out[f"{tag}/err32/{n}"]))
+        # every parameter: the distance of the float32 run from the float64 one (norm-level view of the whole chain)
+        out[f"{tag}/all_names"] = np.array(list(p64))
+        out[f"{tag}/all_err32"] = np.array([_rel(p32[n].grad.numpy(), p64[n].grad.numpy()) for n in p64])
+        out[f"{tag}/all_gnorm64"] = np.array([float(p64[n].grad.norm()) for n in p64])
+        print("G8", tag, "float32 golden vs float64: logits", float(out[f"{tag}/logits_err32"]), "gradient vectors rel L2 min / median / max",
+              min(errs), float(np.median(errs)), max(errs))
+    np.savez_compressed(os.path.join(HERE, "g8_float64.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = dict(g1=g1_luts, g2=g2_sparse2super, g3=g3_encoder2d, g4=g4_losses, g5=g5_full_model, g6=g6_unet,
-               g7=g7_bev_labels)
+               g7=g7_bev_labels, g8=g8_float64)
     for w in which:
         fns[w]()

@@ -180,3 +180,61 @@ def test_minkunet34_matches_reference_golden():
     rel = np.array([abs(float(p.grad.norm()) - float(g6[f"gnorm/{n}"])) / (float(g6[f"gnorm/{n}"]) + 1e-12)
                     for n, p in model.named_parameters()])
     assert np.median(rel) <= 1e-2 and rel.max() <= 1e-1, (np.median(rel), rel.max())  # see the BEV test for why
+
+
+@pytest.mark.parametrize("tag", ["g5", "g6"])
+def test_training_mode_gradients_against_float64_ground_truth(tag):
+    """Training-mode BatchNorm, whole backward chain, against a float64 run of the reference's classes on the oracle
+    (tests/golden/make_golden.py g8).  The yardstick per gradient vector is how far the float32 golden run -- same code,
+    float32 -- sits from that ground truth (`err32`): differences come from ReLU masks (and, with the BEV head, max-pool
+    arg-maxima) of elements within rounding noise of a tie, a handful of which change sides between any two
+    arithmetics.  The HIP path must be at most twice as far from the float64 run as the float32 golden run is; the
+    logits, which no discrete choice amplifies, at most 1e-4 (north_star) and at most twice the golden run's distance."""
+    import lidog_amd
+    import lidog_amd.me as ME
+    from lidog_amd.losses import SoftDICELoss, DICELoss
+    g8 = np.load(f"{GOLDEN}/g8_float64.npz")
+    if tag == "g5":
+        src = np.load(f"{GOLDEN}/g5_minkunet34bev.npz")
+        model = lidog_amd.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5,
+                                        decoder_2d_level=["block8"], mapping_bound_2d=5.0)
+        seed = 5
+    else:
+        src = np.load(f"{GOLDEN}/g6_minkunet34.npz")
+        model = lidog_amd.MinkUNet34(in_channels=1, out_channels=7, D=3)
+        seed = 7
+    C = torch.from_numpy(src["coords"]).cuda()
+    labels = torch.from_numpy(src["labels"]).cuda()
+    model.load_state_dict(seeded_state_dict(model, seed=seed))
+    model.cuda().train()
+    st = ME.SparseTensor(coordinates=C, features=torch.ones((C.shape[0], 1), device="cuda"))
+    if tag == "g5":
+        sem, bev = model(st, is_train=True)
+        bev_labels = torch.from_numpy(src["bev_labels"]).cuda()
+        loss = 0.5 * SoftDICELoss(ignore_label=-1)(sem.F, labels) + \
+            0.5 * DICELoss(ignore_label=-1)(bev["block8"].view(-1, 7), bev_labels.view(-1))
+    else:
+        sem = model(st, is_seg=True)
+        loss = SoftDICELoss(ignore_label=-1)(sem.F, labels)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g8[f"{tag}/loss64"])) <= 1e-5
+    d = (sem.F.detach().cpu().double() - torch.from_numpy(g8[f"{tag}/logits64"]).double()).abs().max().item()
+    assert d <= 1e-4 and d <= 2 * float(g8[f"{tag}/logits_err32"]) + 1e-6, (d, float(g8[f"{tag}/logits_err32"]))
+    named = dict(model.named_parameters())
+    names = [k[len(tag) + 8:] for k in g8.files if k.startswith(f"{tag}/grad64/")]
+    assert len(names) >= 20
+    rep = {}
+    for n in names:
+        ref = torch.from_numpy(g8[f"{tag}/grad64/{n}"]).double().flatten()
+        got = named[n].grad.detach().cpu().double().flatten()
+        rep[n] = (float((got - ref).norm() / ref.norm()), float(g8[f"{tag}/err32/{n}"]))
+    print(f"{tag}: rel L2 distance from the float64 run, HIP / float32 golden:",
+          {n: (f"{a:.1e}", f"{b:.1e}") for n, (a, b) in rep.items()})
+    # float32 storage of the ground truth: 6e-8; below the top ReLU nothing discrete lies in between -> absolute floor
+    bad = {n: v for n, v in rep.items() if v[0] > 2 * v[1] + 2e-6}
+    assert not bad, bad
+    # every parameter of the network: gradient norms against the float64 run, same yardstick
+    all_names = list(g8[f"{tag}/all_names"])
+    ref_norm, err32 = g8[f"{tag}/all_gnorm64"], g8[f"{tag}/all_err32"]
+    dev = np.array([abs(float(named[n].grad.norm()) - r) / r for n, r in zip(all_names, ref_norm)])
+    assert np.all(dev <= 2 * err32 + 2e-6), [(n, d_, e) for n, d_, e in zip(all_names, dev, err32) if d_ > 2 * e + 2e-6][:8]
