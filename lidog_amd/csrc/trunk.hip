@@ -66,6 +66,41 @@ struct Ctx {
 template <typename T>
 inline T *P(int64_t v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v)); }
 
+// ---- data parallelism inside the executor (train_lidog.py:227-231: DDP + MinkowskiSyncBatchNorm).
+// dp [DP_COLS] int64, NULL = single process.  Two transports: native RCCL communicators of this library
+// (csrc/comm.hip; the statistics all-reduce is queued on the launch stream itself, between the reduction and the apply
+// kernel, the gradient buckets on a stream of their own) or a host callback `int cb(int what, int64 a, int64 b)` that
+// performs the collective with whatever the caller has (torch.distributed over gloo in the two-rank tests):
+// what 0 = all-reduce (sum) of b doubles at device address a, in order on the launch stream; 1 = gradient bucket a has
+// all its gradients queued.
+enum { DP_SYNC_BN, DP_COMM_BN, DP_CALLBACK, DP_COMM_GRAD, DP_COMM_STREAM, DP_GRAD_BASE, DP_N_BUCKETS, DP_BUCKETS,
+       DP_PENDING, DP_PARAM_BUCKET, DP_COLS = 12 };
+typedef int (*dp_callback_t)(int32_t what, int64_t a, int64_t b);
+
+struct Dp {
+    const int64_t *d;
+    bool sync_bn() const { return d && d[DP_SYNC_BN] != 0; }
+    bool buckets() const { return d && d[DP_N_BUCKETS] > 0 && d[DP_PENDING] && d[DP_PARAM_BUCKET]; }
+    int check() const {
+        if (!d) return 0;
+        LIDOG_REQUIRE(!d[DP_SYNC_BN] || d[DP_COMM_BN] || d[DP_CALLBACK],
+                      "trunk: SyncBatchNorm statistics need a communicator or a callback");
+        if (d[DP_N_BUCKETS] > 0) {
+            LIDOG_REQUIRE(d[DP_BUCKETS] && d[DP_PENDING] && d[DP_PARAM_BUCKET], "trunk: gradient bucket tables missing");
+            LIDOG_REQUIRE(d[DP_CALLBACK] || (d[DP_COMM_GRAD] && d[DP_COMM_STREAM] && d[DP_GRAD_BASE]),
+                          "trunk: gradient buckets need a communicator with its stream, or a callback");
+        }
+        return 0;
+    }
+    // sum over the ranks of n doubles, in order on `st`
+    int allreduce_f64(double *buf, int64_t n, void *st) const {
+        if (d[DP_COMM_BN]) return lidog_allreduce_f64(buf, n, P<void>(d[DP_COMM_BN]), st);
+        int rc = reinterpret_cast<dp_callback_t>(static_cast<uintptr_t>(d[DP_CALLBACK]))(0, (int64_t)(uintptr_t)buf, n);
+        LIDOG_REQUIRE(rc == 0, "trunk: the statistics all-reduce callback failed (%d)", rc);
+        return 0;
+    }
+};
+
 #define TRY(expr)                 \
     do {                          \
         if (!ctx.dry) {           \
@@ -227,14 +262,16 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                                    int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs,
                                    int32_t n_bufs, const int64_t *level_rows, const int64_t *ext, void *arena,
                                    int64_t arena_bytes, void *scratch, int64_t scratch_bytes, int64_t *rec,
-                                   int64_t *need, int32_t dry, void *stream) {
+                                   int64_t *need, int32_t dry, const int64_t *dp_desc, void *stream) {
     Ctx ctx{convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows, ext, dry != 0};
+    Dp dp{dp_desc};
     if (int rc = check_tables(ctx, false)) return rc;
+    if (int rc = dp.check()) return rc;
     if (!ctx.dry) {
         // sizes first: nothing is launched into an arena that is too small
         int64_t want[2];
         if (int rc = lidog_trunk_forward(convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows,
-                                         ext, nullptr, 0, nullptr, 0, rec, want, 1, stream))
+                                         ext, nullptr, 0, nullptr, 0, rec, want, 1, dp_desc, stream))
             return rc;
         LIDOG_REQUIRE(arena && scratch && want[0] <= arena_bytes && want[1] <= scratch_bytes,
                       "trunk: forward needs %lld B of arena and %lld B of scratch, got %lld / %lld", (long long)want[0],
@@ -258,15 +295,23 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             bp[b] = (float *)ar.take(ctx.bytes(b));
         }
     }
-    for (int o = 0; o < n_ops; ++o) {
+    // One convolution (+ the statistics of its BatchNorm) and, separately, the BatchNorm's finalise + apply: under
+    // SyncBatchNorm an all-reduce of the statistics sits between the two, and the first block of a layer sends the
+    // statistics of conv1 and of its 1x1 downsample convolution (both read the block input) in ONE message
+    // (me.BasicBlock._forward_joint_sync).
+    struct Pending {
+        const int64_t *op, *c;
+        float *pre, *mean, *invstd, *y;
+        double *sums;
+        int64_t n;
+        int Cout;
+        float eps, mom;
+    };
+    const bool sync = dp.sync_bn();
+    // sums_at: where this layer's (sum x, sum x^2, rows) go when they are part of a joint message, else NULL
+    auto conv_part = [&](int o, double *sums_at, Pending &pd) -> int {
         const int64_t *op = ops + (int64_t)o * TO_COLS;
         int64_t *r = rec + (int64_t)o * REC_COLS;
-        sc.reset();
-        if (op[TO_TYPE] == OP_CAT) {
-            int a = (int)op[TO_IN], b = (int)op[TO_B];
-            TRY(lidog_cat2(bp[a], ctx.ch(a), bp[b], ctx.ch(b), ctx.rows(a), bp[op[TO_OUT]], stream));
-            continue;
-        }
         const int64_t *c = convs + op[TO_CONV] * TC_COLS;
         const int64_t *m = maps + c[TC_MAP] * TM_COLS;
         const int kind = (int)c[TC_KIND], Cin = (int)c[TC_CIN], Cout = (int)c[TC_COUT], K = (int)c[TC_K];
@@ -286,6 +331,13 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             invstd = (float *)ar.take(Cout * 4);
         }
         float *rm = P<float>(c[TC_BNRM]), *rv = P<float>(c[TC_BNRV]);
+        double *sums = nullptr;
+        if (bn) sums = sums_at ? sums_at : (double *)sc.take((2 * Cout + 1) * 8);
+        // local BatchNorm: the reduction's last kernel finalises mean / invstd / running statistics; SyncBatchNorm:
+        // sums and row count only, finalised after the all-reduce
+        float *f_mean = sync ? nullptr : mean, *f_invstd = sync ? nullptr : invstd;
+        float *f_rm = sync ? nullptr : rm, *f_rv = sync ? nullptr : rv;
+        const float f_eps = sync ? 0.f : eps, f_mom = sync ? 0.f : mom;
         bool stats_done = false;
         if (kind == KIND_K3 || kind == KIND_DOWN) {
             // gathered GEMM into product rows, per-row reduction (+ BatchNorm statistics in its epilogue)
@@ -294,10 +346,9 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                 return rc;
             const int32_t *rp = P<const int32_t>(m[TM_RP_OUT]), *rl = P<const int32_t>(m[TM_RL_OUT]);
             if (bn) {
-                double *sums = (double *)sc.take((2 * Cout + 1) * 8);
                 double *ws = (double *)sc.take(lidog_sconv_reduce_stats_ws(n, Cout) * 8);
-                TRYX(2, lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, eps, mom, mean,
-                                                  invstd, rm, rv, stream));
+                TRYX(2, lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, f_eps, f_mom,
+                                                      f_mean, f_invstd, f_rm, f_rv, stream));
                 stats_done = true;
             } else {
                 TRY(lidog_sconv_reduce_rows(T, rp, rl, n, Cout, bias, nullptr, pre, stream));
@@ -312,16 +363,53 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         } else {
             TRY(lidog_sconv_cin1(x, P<const int32_t>(m[TM_NBR]), W, bias, n, K, Cout, pre, stream));
         }
-        if (!bn) continue;
-        if (!stats_done) {
-            double *sums = (double *)sc.take((2 * Cout + 1) * 8);
+        if (bn && !stats_done) {
             int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
             double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-            TRYX(4, lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, eps, mom, mean, invstd, rm, rv, stream));
+            TRYX(4, lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
         }
+        pd = Pending{op, c, pre, mean, invstd, y, sums, n, Cout, eps, mom};
+        return 0;
+    };
+    auto bn_part = [&](const Pending &pd) -> int {
+        const int64_t *op = pd.op, *c = pd.c;
+        if (sync)   // the global count sits behind the sums (count <= 0: read from the device)
+            TRY(lidog_bn_finalize(pd.sums, -1.0, pd.Cout, pd.eps, pd.mom, pd.mean, pd.invstd, P<float>(c[TC_BNRM]),
+                                  P<float>(c[TC_BNRV]), stream));
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
-        TRYX(4, lidog_bn_apply(pre, n, Cout, 1, mean, invstd, P<const float>(c[TC_BNW]), P<const float>(c[TC_BNB]), res,
-                           (int32_t)op[TO_RELU], y, stream));
+        TRYX(4, lidog_bn_apply(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
+                               P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, stream));
+        return 0;
+    };
+    for (int o = 0; o < n_ops; ++o) {
+        const int64_t *op = ops + (int64_t)o * TO_COLS;
+        sc.reset();
+        if (op[TO_TYPE] == OP_CAT) {
+            int a = (int)op[TO_IN], b = (int)op[TO_B];
+            TRY(lidog_cat2(bp[a], ctx.ch(a), bp[b], ctx.ch(b), ctx.rows(a), bp[op[TO_OUT]], stream));
+            continue;
+        }
+        Pending pd;
+        // conv1 of a block followed by the block's downsample convolution on the same input: joint statistics message
+        const int64_t *nx = o + 1 < n_ops ? ops + (int64_t)(o + 1) * TO_COLS : nullptr;
+        const bool joint = sync && op[TO_TYPE] == OP_CONVBN && op[TO_FOLD] && nx && nx[TO_TYPE] == OP_CONVBN &&
+                           nx[TO_IN] == op[TO_IN] && convs[nx[TO_CONV] * TC_COLS + TC_KIND] == KIND_1X1;
+        if (joint) {
+            const int Ca = (int)convs[op[TO_CONV] * TC_COLS + TC_COUT], Cd = (int)convs[nx[TO_CONV] * TC_COLS + TC_COUT];
+            double *msg = (double *)sc.take((int64_t)(2 * Ca + 1 + 2 * Cd + 1) * 8);
+            Pending pd2;
+            if (int rc = conv_part(o, msg, pd)) return rc;
+            if (int rc = conv_part(o + 1, msg + 2 * Ca + 1, pd2)) return rc;
+            TRY(dp.allreduce_f64(msg, 2 * Ca + 1 + 2 * Cd + 1, stream));
+            if (int rc = bn_part(pd)) return rc;
+            if (int rc = bn_part(pd2)) return rc;
+            ++o;
+            continue;
+        }
+        if (int rc = conv_part(o, nullptr, pd)) return rc;
+        if (op[TO_TYPE] != OP_CONVBN) continue;
+        if (sync) TRY(dp.allreduce_f64(pd.sums, 2 * pd.Cout + 1, stream));
+        if (int rc = bn_part(pd)) return rc;
     }
     need[0] = ar.peak;
     need[1] = sc.peak;

@@ -233,6 +233,13 @@ def test_training_mode_gradients_against_float64_ground_truth(tag):
     # float32 storage of the ground truth: 6e-8; below the top ReLU nothing discrete lies in between -> absolute floor
     bad = {n: v for n, v in rep.items() if v[0] > 2 * v[1] + 2e-6}
     assert not bad, bad
+    # Absolute bars (measured: 4e-7 .. 1.6e-6 down to block7 -- no mask has changed sides yet --, <= 3.8e-3 below): the
+    # HIP path sums BatchNorm statistics in float64 and sits 20-50 x closer to the float64 run than the float32 golden
+    # run does (torch's float32 BatchNorm sums; with the BEV head, max-pool arg-maxima of near-ties).  A wrong term in
+    # BatchNorm backward moves every vector below it by far more than these bars.
+    top = [n for n in rep if n.startswith(("block7", "block8", "convtr7", "final", "encoders2d"))]
+    assert len(top) >= 5 and max(rep[n][0] for n in top) <= 1e-5, {n: rep[n] for n in top}
+    assert max(v[0] for v in rep.values()) <= 8e-3, rep
     # every parameter of the network: gradient norms against the float64 run, same yardstick
     all_names = list(g8[f"{tag}/all_names"])
     ref_norm, err32 = g8[f"{tag}/all_gnorm64"], g8[f"{tag}/all_err32"]
