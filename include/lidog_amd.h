@@ -129,6 +129,17 @@ int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_ptr, const 
                                   int32_t C, const float *bias, float *out, double *sums, double *partial_ws,
                                   double count, float eps, float momentum, float *mean, float *invstd,
                                   float *running_mean, float *running_var, void *stream);
+/* Data-gradient reduction (lidog_sconv_reduce_rows without bias) whose epilogue is lidog_bn_bwd_reduce of the layer that
+ * produced the rows: `out` is the complete gradient dy of that layer's BatchNorm (+ ReLU) output
+ * (ME.MinkowskiBatchNorm backward, minkunet_bev.py:60), `pre` / mean / invstd its saved input and statistics,
+ * relu_y or (relu_w, relu_b) its ReLU mask as in lidog_bn_bwd_reduce.  sums / count / dw / db as there; the sums are
+ * bit-identical to calling lidog_bn_bwd_reduce on `out` afterwards (same partial sums in the same order), one pass
+ * over dy less.  partial_ws: lidog_bn_reduce_ws(C, 1) doubles. */
+int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
+                                     int32_t C, const float *addend, float *out, const float *pre,
+                                     const float *relu_y, const float *mean, const float *invstd,
+                                     const float *relu_w, const float *relu_b, double *sums, double *partial_ws,
+                                     double count, float *dw, float *db, void *stream);
 /* Validation path (running statistics, minkunet_bev.py:376-393): the reduction with the evaluation-mode BatchNorm
  * (+ residual + ReLU) in its epilogue, same expression and order as lidog_bn_apply. */
 int lidog_sconv_reduce_rows_bn(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n, int32_t C,
@@ -218,6 +229,8 @@ int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float
 /* relu_w / relu_b (both or neither; relu_y must then be NULL; [rows, C] with C % 4 == 0 only): the ReLU mask is
  * recomputed from x with the forward pass's own expression ((x - mean) * invstd * w + b > 0, same bits) instead of
  * being read from the saved output -- for a BatchNorm + ReLU WITHOUT residual, one tensor less to stream. */
+/* workgroups (= rows of partial sums) lidog_bn_bwd_reduce uses for [n, C] rows, C % 4 == 0 */
+int64_t lidog_bn_bwd_reduce_blocks(int64_t n, int32_t C);
 int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                         const float *mean, const float *invstd, double *sums, double *ws, double count, float *dw,
                         float *db, const float *relu_w, const float *relu_b, void *stream);
@@ -395,12 +408,29 @@ int64_t lidog_wgrad_items_host(const int64_t *k_off_host, int32_t K, int64_t chu
  *         gradients (0 = none)
  * Memory: see the notes on arena / garena / scratch / lane_scratch in csrc/trunk.hip.  dry != 0: nothing is launched,
  * need[] receives the bytes of each region for this batch.  rec [n_ops * 4 + n_bufs]: written by forward, read by
- * backward (arena offsets).  Training-mode BatchNorm with local statistics only (SyncBatchNorm: operator path). */
+ * backward (arena offsets).  Training-mode BatchNorm.
+ *
+ * Data parallelism (train_lidog.py:227-231: Lightning DDP + MinkowskiSyncBatchNorm.convert_sync_batchnorm) --
+ * dp [12] int64, NULL = single process:
+ *   [0] SyncBatchNorm on: every BatchNorm's (sum, sum, rows) message is summed over the ranks between the kernel that
+ *       produces it and the kernel that consumes it (forward: statistics -> finalise + apply, one message for conv1 +
+ *       downsample of a block; backward: reduce -> apply), IN ORDER ON `stream`
+ *   [1] communicator for those messages (lidog_comm_init_rank) or 0
+ *   [2] host callback `int cb(int32_t what, int64_t a, int64_t b)` or 0, used where a communicator is 0:
+ *       what 0 = all-reduce (sum) of b doubles at device address a, ordered on `stream`; what 1 = gradient bucket a
+ *       has all its gradients queued (the callee reduces it)
+ *   [3] communicator of the gradient buckets, [4] its hipStream_t, [5] base of the flat fp32 gradient buffer
+ *   [6] number of buckets (0 = none), [7] int64 [n][2] element ranges (lo, hi) of the buckets in that buffer,
+ *   [8] int32 [n] HOST countdown per bucket (gradients still missing; shared with the caller, who counts the
+ *       parameters that are not the trunk's), [9] int32 [n_convs][4] HOST: bucket of (kernel, bias, BatchNorm weight,
+ *       BatchNorm bias) of every convolution or -1.
+ * A bucket whose countdown reaches 0 inside lidog_trunk_backward is all-reduced (sum) on its stream behind events
+ * recorded on `stream` and `lane`; the caller makes its optimiser step wait for that stream. */
 int lidog_trunk_forward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
                         int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs,
                         const int64_t *level_rows, const int64_t *ext, void *arena, int64_t arena_bytes,
                         void *scratch, int64_t scratch_bytes, int64_t *rec, int64_t *need /*[2]*/, int32_t dry,
-                        void *stream);
+                        const int64_t *dp /*[12] or NULL*/, void *stream);
 /* lane: second stream for the weight gradients (NULL = in line), forked behind each data gradient's GEMM
  * (wgrad_first = 0) or before it; joined into `stream` before the call returns. */
 int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
@@ -409,7 +439,12 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
                          const int64_t *rec, void *garena, int64_t garena_bytes, void *scratch,
                          int64_t scratch_bytes, void *lane_scratch, int64_t lane_bytes, int64_t *need /*[3]*/,
                          int32_t *conv_done_host /*[n_convs]: 1 = this convolution's parameter gradients were written*/,
-                         int32_t dry, int32_t wgrad_first, void *stream, void *lane);
+                         int32_t dry, int32_t wgrad_first, const int64_t *dp /*[12] or NULL*/, void *stream,
+                         void *lane);
+/* Fusions the executor applies on top of the operator path's launch sequence (bit mask; results are bit-identical
+ * either way): 1 = BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction
+ * (lidog_sconv_reduce_rows_bwdstats).  mask >= 0 sets it; returns the previous mask. */
+int32_t lidog_trunk_fusions(int32_t mask);
 /* Timing of the executor's gathered-GEMM launches for the roofline figure of bench.py: on != 0 brackets every such
  * launch with HIP events on its stream; _read waits for the recorded launches, returns (launches, total ms, algorithmic
  * FLOPs, algorithmic bytes: SURVEY.md 8(d)) in out[0..3] and forgets them.  One timing client per process. */

@@ -239,6 +239,16 @@ __global__ __launch_bounds__(256) void k_colreduce_strided(const float *__restri
 
 static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4 == 0 && C / 4 <= 256; }
 #define COLREDUCE_MAX_BLOCKS 512
+// The backward reduction over [rows, C] takes the grid of the per-row convolution reductions (one row per thread until
+// 2048 workgroups are reached, then a grid-stride loop): the data-gradient reduction that produces dy can then
+// accumulate the same partials in its epilogue, bit for bit (sconv.hip:k_sconv_reduce_rows4_bwdstats)
+#define COLREDUCE_BWD_MAX_BLOCKS 2048
+
+extern "C" int64_t lidog_bn_bwd_reduce_blocks(int64_t n, int32_t C) {
+    const int RB = 256 / (C / 4);
+    int64_t nb = cdiv64(n, (int64_t)RB);
+    return nb > COLREDUCE_BWD_MAX_BLOCKS ? COLREDUCE_BWD_MAX_BLOCKS : (nb < 1 ? 1 : nb);
+}
 
 template <int MODE>
 static int launch_colreduce(const float *x, const float *dy, const float *ry, int64_t n, int C, int64_t hw,
@@ -255,6 +265,7 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
 #endif
         int64_t nb = cdiv64(n, (int64_t)RB * 4 * COLREDUCE_ROUNDS);
         if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
+        if (MODE == 1) nb = lidog_bn_bwd_reduce_blocks(n, C);
         k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
                                                             n, C4, mean, invstd, ws, rw, rb);
         lidog_launch_sums_finish(ws, (int)nb, C, sums, count, fin, st);
@@ -281,7 +292,7 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
 }
 
 extern "C" int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw) {
-    return colreduce_uses_partials(C, hw) ? (int64_t)COLREDUCE_MAX_BLOCKS * 2 * C : 0;
+    return colreduce_uses_partials(C, hw) ? (int64_t)COLREDUCE_BWD_MAX_BLOCKS * 2 * C : 0;
 }
 
 extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws, double count,

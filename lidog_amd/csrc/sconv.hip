@@ -538,6 +538,100 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *
     }
 }
 
+// Data-gradient reduction whose epilogue is the BatchNorm-backward reduction of the layer that PRODUCED the rows it
+// writes: out[o] = sum of T rows (+ addend) is the complete gradient dy of that layer's BatchNorm output, so
+// (sum dy', sum dy' * xhat) -- dy' = dy masked by the layer's ReLU, xhat from its saved pre-normalisation rows -- can be
+// accumulated while dy is still in registers instead of by a second pass over dy (bn.hip:k_colreduce_nc4<1>, which then
+// is not launched).  Same row -> (workgroup, thread) assignment, same per-thread order, same LDS tree and the same
+// terms (red_terms<1>) as that kernel at the same grid size, and the partials go through the same finishing kernel:
+// the sums are bit-identical to the two-pass path.
+__global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
+    const float4 *__restrict__ T, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_list, int64_t n,
+    int C4, const float4 *__restrict__ addend, float4 *__restrict__ out, const float4 *__restrict__ pre,
+    const float4 *__restrict__ relu_y, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ rw, const float *__restrict__ rb, double *__restrict__ partial) {
+    __shared__ double red[256 * 8];
+    const int RB = 256 / C4;
+    const int tid = threadIdx.x;
+    const int r = tid / C4, c4 = tid % C4;
+    const bool active = r < RB;
+    const bool from_x = relu_y == nullptr && rw != nullptr;
+    const bool has_relu = relu_y != nullptr || from_x;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        float m[4], is[4], gw[4] = {0, 0, 0, 0}, gb[4] = {1, 1, 1, 1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = mean[c4 * 4 + j]; is[j] = invstd[c4 * 4 + j]; }
+        if (from_x) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gw[j] = rw[c4 * 4 + j]; gb[j] = rb[c4 * 4 + j]; }
+        }
+        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += (int64_t)gridDim.x * RB) {
+            const int64_t idx = o * C4 + c4;
+            const float4 x = pre[idx];
+            float4 y = relu_y ? relu_y[idx] : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 g = reduce_row_list(T, row_ptr, row_list, C4, o, c4);
+            if (addend) {
+                const float4 ad = addend[idx];
+                g.x += ad.x; g.y += ad.y; g.z += ad.z; g.w += ad.w;
+            }
+            out[idx] = g;
+            if (from_x) {   // the forward pass's pre-activation, bit for bit (bn.hip:k_bn_apply4)
+                y.x = (x.x - m[0]) * is[0] * gw[0] + gb[0];
+                y.y = (x.y - m[1]) * is[1] * gw[1] + gb[1];
+                y.z = (x.z - m[2]) * is[2] * gw[2] + gb[2];
+                y.w = (x.w - m[3]) * is[3] * gw[3] + gb[3];
+            }
+            const float xv[4] = {x.x, x.y, x.z, x.w}, gv[4] = {g.x, g.y, g.z, g.w}, yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // = bn.hip:red_terms<1>
+                const float gg = (has_relu && !(yv[j] > 0.f)) ? 0.f : gv[j];
+                const float xh = (xv[j] - m[j]) * is[j];
+                a[j] += (double)gg;
+                a[4 + j] += (double)gg * (double)xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
+    __syncthreads();
+    if (active && r == 0) {
+        const int C = C4 * 4;
+        for (int rr = 1; rr < RB; ++rr)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
+        double *dst = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[c4 * 4 + j] = a[j];
+            dst[C + c4 * 4 + j] = a[4 + j];
+        }
+    }
+}
+
+extern "C" int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *row_ptr, const int32_t *row_list,
+                                                int64_t n, int32_t C, const float *addend, float *out,
+                                                const float *pre, const float *relu_y, const float *mean,
+                                                const float *invstd, const float *relu_w, const float *relu_b,
+                                                double *sums, double *partial_ws, double count, float *dw, float *db,
+                                                void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconv_reduce_rows_bwdstats: C must be a multiple of 4, <= 1024");
+    LIDOG_REQUIRE(pre && mean && invstd && sums && partial_ws, "sconv_reduce_rows_bwdstats: null argument");
+    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) && !(relu_y && relu_w),
+                  "sconv_reduce_rows_bwdstats: pass either relu_y or (relu_w, relu_b)");
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
+    const int C4 = C / 4;
+    const int64_t nb = lidog_bn_bwd_reduce_blocks(n, C);   // the grid of lidog_bn_bwd_reduce: same partials
+    k_sconv_reduce_rows4_bwdstats<<<(unsigned)nb, 256, 0, st>>>(
+        (const float4 *)T, row_ptr, row_list, n, C4, (const float4 *)addend, (float4 *)out, (const float4 *)pre,
+        (const float4 *)relu_y, mean, invstd, relu_w, relu_b, partial_ws);
+    BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
+    lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 // The same reduction with an evaluation-mode BatchNorm (+ residual + ReLU) applied in the epilogue: the validation path
 // (minkunet_bev.py:376-393, running statistics) needs no statistics pass, so the separate BatchNorm kernel and one
 // write + read of the convolution output go away.  Same expression and operation order as bn.hip:k_bn_apply4.

@@ -205,6 +205,10 @@ int check_tables(const Ctx &ctx, bool grads) {
 
 inline const int32_t *tile_row(const int64_t *m, int r) { return P<const int32_t>(m[TM_TILES]) + r * m[TM_NTILES]; }
 
+// Fusions the executor applies on top of the operator path's launch sequence (results stay bit-identical):
+//   1 = BatchNorm-backward statistics in the epilogue of the data-gradient reduction that produces the gradient
+int g_fusions = 1;
+
 // Optional timing of the gathered GEMM's launches (bench.py's roofline figure): HIP events on the launch stream around
 // every lidog_sconv_gemm call of the executor, with the launch's algorithmic FLOPs and bytes (every distinct input row
 // and weight read once, every product row written once, the gather index read once: SURVEY.md 8(d)).
@@ -428,14 +432,16 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                                     const int64_t *ext_grad, void *arena, const int64_t *rec, void *garena,
                                     int64_t garena_bytes, void *scratch, int64_t scratch_bytes, void *lane_scratch,
                                     int64_t lane_bytes, int64_t *need, int32_t *conv_done, int32_t dry,
-                                    int32_t wgrad_first, void *stream, void *lane) {
+                                    int32_t wgrad_first, const int64_t *dp_desc, void *stream, void *lane) {
     Ctx ctx{convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows, ext, dry != 0};
+    Dp dp{dp_desc};
     if (int rc = check_tables(ctx, true)) return rc;
+    if (int rc = dp.check()) return rc;
     if (!ctx.dry) {
         int64_t want[3];
         if (int rc = lidog_trunk_backward(convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows,
                                           ext, ext_grad, arena, rec, nullptr, 0, nullptr, 0, nullptr, 0, want,
-                                          conv_done, 1, wgrad_first, stream, lane))
+                                          conv_done, 1, wgrad_first, dp_desc, stream, lane))
             return rc;
         LIDOG_REQUIRE(arena && garena && scratch && (lane_scratch || !lane) && want[0] <= garena_bytes &&
                           want[1] <= scratch_bytes && want[2] <= lane_bytes,
@@ -450,10 +456,42 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     g_gemm_bit = 32;
 #endif
     hipEvent_t *events = nullptr;
-    if (lane && !ctx.dry) {
-        events = event_pool(n_convs + 1);
+    const bool sync = dp.sync_bn(), buckets = dp.buckets() && !ctx.dry;
+    const int n_buckets = buckets ? (int)dp.d[DP_N_BUCKETS] : 0;
+    if ((lane || buckets) && !ctx.dry) {
+        // [0, n_convs): lane forks; n_convs: the final join; then two per gradient bucket (main / lane -> bucket stream)
+        events = event_pool(n_convs + 1 + 2 * n_buckets);
         LIDOG_REQUIRE(events, "trunk: cannot create events");
     }
+    // A gradient bucket (a contiguous slice of the flat gradient buffer, lidog_amd.optim.GradientBuckets) is reduced as
+    // soon as the last gradient of its parameters has been QUEUED: the bucket stream waits for what the launch stream
+    // and the lane stream hold at that moment, nothing ever waits for the bucket stream here (the caller joins it
+    // before the optimiser step).  pending[b] is shared with the caller, whose own parameters (the 2-D head) count
+    // down in the same array from their gradient hooks.
+    auto param_done = [&](int64_t conv, int slot) -> int {
+        if (!buckets) return 0;
+        const int b = P<const int32_t>(dp.d[DP_PARAM_BUCKET])[conv * 4 + slot];
+        if (b < 0) return 0;
+        LIDOG_REQUIRE(b < n_buckets, "trunk: parameter of convolution %lld in bucket %d of %d", (long long)conv, b, n_buckets);
+        int32_t *pending = P<int32_t>(dp.d[DP_PENDING]);
+        if (--pending[b] != 0) return 0;
+        if (!dp.d[DP_COMM_GRAD]) {
+            int rc = reinterpret_cast<dp_callback_t>(static_cast<uintptr_t>(dp.d[DP_CALLBACK]))(1, b, 0);
+            LIDOG_REQUIRE(rc == 0, "trunk: the gradient bucket callback failed (%d)", rc);
+            return 0;
+        }
+        hipStream_t cst = (hipStream_t)P<void>(dp.d[DP_COMM_STREAM]);
+        hipEvent_t e_main = events[n_convs + 1 + 2 * b], e_lane = events[n_convs + 2 + 2 * b];
+        LIDOG_CHECK_HIP(hipEventRecord(e_main, main_st));
+        LIDOG_CHECK_HIP(hipStreamWaitEvent(cst, e_main, 0));
+        if (lane) {   // every bucket waits for the lane as it stands: stream order then covers all earlier weight gradients
+            LIDOG_CHECK_HIP(hipEventRecord(e_lane, lane_st));
+            LIDOG_CHECK_HIP(hipStreamWaitEvent(cst, e_lane, 0));
+        }
+        const int64_t *sl = P<const int64_t>(dp.d[DP_BUCKETS]) + 2 * b;
+        return lidog_allreduce_f32(P<float>(dp.d[DP_GRAD_BASE]) + sl[0], sl[1] - sl[0], P<void>(dp.d[DP_COMM_GRAD]), cst);
+    };
+
     const int64_t *buf_off = rec + (int64_t)n_ops * REC_COLS;
     std::vector<float *> bp(n_bufs, nullptr);
     // gradient slot of every buffer: 0 = nothing yet, 1 = the caller's tensor (read only), 2 = ours (garena)
@@ -487,6 +525,17 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     };
     int lane_used = 0;
     for (int i = 0; i < n_convs; ++i) conv_done[i] = 0;
+    // producer of every buffer and its first consumer in forward order = the LAST one to add to its gradient here
+    std::vector<int> producer(n_bufs, -1), first_consumer(n_bufs, n_ops);
+    for (int o = n_ops - 1; o >= 0; --o) {
+        const int64_t *op = ops + (int64_t)o * TO_COLS;
+        producer[op[TO_OUT]] = o;
+        first_consumer[op[TO_IN]] = o;
+        if (op[TO_TYPE] == OP_CAT) first_consumer[op[TO_B]] = o;
+        if (op[TO_TYPE] == OP_CONVBN && op[TO_RES] >= 0) first_consumer[op[TO_RES]] = o;
+    }
+    // BatchNorm-backward sums of op o already produced by the reduction that completed its output gradient
+    std::vector<double *> bwd_sums(n_ops, nullptr);
     for (int o = n_ops - 1; o >= 0; --o) {
         const int64_t *op = ops + (int64_t)o * TO_COLS;
         const int64_t *r = rec + (int64_t)o * REC_COLS;
@@ -515,16 +564,21 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             const bool mask_from_x = relu && !has_res;  // Cout % 4 == 0 checked above
             const float *ymask = (relu && !mask_from_x) ? bp[out_b] : nullptr;
             const float *bnw = P<const float>(c[TC_BNW]), *bnb = P<const float>(c[TC_BNB]);
-            double *sums = (double *)sc.take((2 * Cout + 1) * 8);
-            int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
-            double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-            TRYX(8, lidog_bn_bwd_reduce(gout, pre, ymask, n, Cout, 1, mean, invstd, sums, ws, (double)n, P<float>(c[TC_GBNW]),
-                                    P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr, mask_from_x ? bnb : nullptr,
-                                    stream));
+            double *sums = bwd_sums[o];
+            if (!sums) {
+                sums = (double *)sc.take((2 * Cout + 1) * 8);
+                int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
+                double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
+                TRYX(8, lidog_bn_bwd_reduce(gout, pre, ymask, n, Cout, 1, mean, invstd, sums, ws, (double)n,
+                                            P<float>(c[TC_GBNW]), P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr,
+                                            mask_from_x ? bnb : nullptr, stream));
+            }
             float *dx = (float *)ga.take(n * Cout * 4);
             float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
-            TRYX(16, lidog_bn_bwd_apply(gout, pre, ymask, n, Cout, 1, mean, invstd, bnw, sums, (double)n, dx, dres, nullptr,
-                                   nullptr, mask_from_x ? bnb : nullptr, stream));
+            // SyncBatchNorm: (sum dy', sum dy' xhat, rows) summed over the ranks; the apply kernel reads the global count
+            if (sync) TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
+            TRYX(16, lidog_bn_bwd_apply(gout, pre, ymask, n, Cout, 1, mean, invstd, bnw, sums, sync ? -1.0 : (double)n, dx,
+                                   dres, nullptr, nullptr, mask_from_x ? bnb : nullptr, stream));
             if (has_res)
                 if (int rc = commit((int)op[TO_RES], dres)) return rc;
             gout = dx;
@@ -595,7 +649,33 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 const int32_t *rp = P<const int32_t>(kind == KIND_UP ? m[TM_RP_OUT] : m[TM_RP_IN]);
                 const int32_t *rl = P<const int32_t>(kind == KIND_UP ? m[TM_RL_OUT] : m[TM_RL_IN]);
                 float *gx = target(in_b);
-                if (op[TO_FOLD] && gs[in_b] != 0) {
+                // This reduction completes the gradient of in_b when nothing reaches that buffer after it: it is the
+                // buffer's first consumer in forward order, and whatever arrived before is either absent or enters
+                // as the addend.  If a BatchNorm produced the buffer, its backward sums ride in the epilogue.
+                const int po = producer[in_b];
+                const bool folds = op[TO_FOLD] && gs[in_b] != 0;
+                const int64_t *pop = po >= 0 ? ops + (int64_t)po * TO_COLS : nullptr;
+                if ((g_fusions & 1) && pop && pop[TO_TYPE] == OP_CONVBN && first_consumer[in_b] == o &&
+                    (folds || gs[in_b] == 0) && Cin % 4 == 0 && Cin / 4 <= 256) {
+                    const int64_t *pc = convs + pop[TO_CONV] * TC_COLS;
+                    const int64_t *pr = rec + (int64_t)po * REC_COLS;
+                    const float *p_pre = ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_PRE]);
+                    const float *p_mean = ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_MEAN]);
+                    const float *p_invstd = ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_INVSTD]);
+                    const bool p_relu = pop[TO_RELU] != 0, p_from_x = p_relu && pop[TO_RES] < 0;
+                    const float *p_y = (p_relu && !p_from_x) ? bp[in_b] : nullptr;
+                    double *sums = (double *)ga.take((2 * Cin + 1) * 8);   // lives until the producer's turn
+                    double *ws = (double *)sc.take(lidog_bn_reduce_ws(Cin, 1) * 8);
+                    TRYX(64, lidog_sconv_reduce_rows_bwdstats(T, rp, rl, n_in, Cin, folds ? gp[in_b] : nullptr, gx, p_pre,
+                                                              p_y, p_mean, p_invstd,
+                                                              p_from_x ? P<const float>(pc[TC_BNW]) : nullptr,
+                                                              p_from_x ? P<const float>(pc[TC_BNB]) : nullptr, sums, ws,
+                                                              (double)n_in, P<float>(pc[TC_GBNW]), P<float>(pc[TC_GBNB]),
+                                                              stream));
+                    bwd_sums[po] = sums;
+                    gp[in_b] = gx;
+                    gs[in_b] = 2;
+                } else if (folds) {
                     // the residual branch's gradient of the block input enters the sum in the reduction's epilogue
                     TRYX(64, lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
                     gp[in_b] = gx;
@@ -612,6 +692,17 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             double *ws = (double *)sc.take(lidog_colsum_ws(Cout) * 8);
             TRY(lidog_colsum(gout, n, Cout, P<float>(c[TC_GBIAS]), ws, stream));
         }
+        // every parameter gradient of this convolution is queued now (kernel: lane or launch stream; bias and BatchNorm
+        // gains / biases: launch stream)
+        if (!ctx.dry) {
+            if (int rc = param_done(op[TO_CONV], 0)) return rc;
+            if (c[TC_BIAS] && c[TC_GBIAS])
+                if (int rc = param_done(op[TO_CONV], 1)) return rc;
+            if (op[TO_TYPE] == OP_CONVBN) {
+                if (int rc = param_done(op[TO_CONV], 2)) return rc;
+                if (int rc = param_done(op[TO_CONV], 3)) return rc;
+            }
+        }
     }
     if (lane_used && !ctx.dry) {
         hipEvent_t ev = events[n_convs];
@@ -622,6 +713,13 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     need[1] = sc.peak;
     need[2] = ls.peak;
     return 0;
+}
+
+// Which fusions the executor applies (bit mask, see g_fusions; default: all).  Returns the previous mask; < 0 only reads.
+extern "C" int32_t lidog_trunk_fusions(int32_t mask) {
+    int32_t old = g_fusions;
+    if (mask >= 0) g_fusions = mask;
+    return old;
 }
 
 // Timing of the executor's gathered-GEMM launches (see GemmRec above).  on != 0: every launch from now on is bracketed

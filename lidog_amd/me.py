@@ -1017,8 +1017,8 @@ class _BatchNormFn(torch.autograd.Function):
                          float(momentum), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var))
             if sync:
                 if not presynced:
-                    import torch.distributed as dist
-                    dist.all_reduce(sums, group=group)   # (sum x, sum x^2, rows) in ONE message
+                    from .comm import transport
+                    transport(group).allreduce_f64(sums)   # (sum x, sum x^2, rows) in ONE message
                 count = -1.0                              # consumers read the global count from sums[2C]
             if mean is None:
                 mean = torch.empty(C, dtype=torch.float32, device=dev)
@@ -1064,8 +1064,8 @@ class _BatchNormFn(torch.autograd.Function):
         if not training:
             sums.zero_()  # running statistics are constants: dx = dy' * w * invstd
         elif group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=group)   # (sum dy', sum dy' xhat, rows)
+            from .comm import transport
+            transport(group).allreduce_f64(sums)   # (sum dy', sum dy' xhat, rows)
             count = -1.0
         call("lidog_bn_bwd_apply", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(weight),
              ptr(sums), count, ptr(dx), ptr(dres), None, None, ptr(mask_b))
@@ -1429,7 +1429,7 @@ class BasicBlock(nn.Module):
         """First block of a layer under SyncBatchNorm: conv1 and the 1x1 downsample convolution both read x and are
         independent, so the statistics of their two BatchNorms travel in ONE all-reduce (7 collectives fewer per
         forward pass; a statistics all-reduce is pure latency on the dependent chain)."""
-        import torch.distributed as dist
+        from .comm import transport
         bn1, (convd, bnd) = self.norm1, self.downsample
         Ca, Cd = bn1.bn.num_features, bnd.bn.num_features
         joint = torch.empty(2 * Ca + 1 + 2 * Cd + 1, dtype=torch.float64, device=x.F.device)
@@ -1448,7 +1448,7 @@ class BasicBlock(nn.Module):
         call("lidog_bn_stats", ptr(yd.F), yd.F.shape[0], Cd, 1, ptr(sums_d), ptr(_bn_ws(Cd, 1, yd.F.device)),
              float(yd.F.shape[0]), 0.0, 0.0, None, None, None, None)
         req_d.sums = sums_d
-        dist.all_reduce(joint, group=group)
+        transport(group).allreduce_f64(joint)
         req_a.presynced = req_d.presynced = True
         out = bn1(y1, relu=True, stats=req_a)
         residual = bnd(yd, stats=req_d)

@@ -13,11 +13,12 @@ Parameters, gradients and optimiser state live in contiguous fp32 buffers: one f
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import me as ME
-from ._lib import call, ptr
+from ._lib import call, call_on, ptr
 
 
 class FlatParams:
@@ -32,6 +33,7 @@ class FlatParams:
         self.offsets = []
         self.generation = 0
         self.hooked = False
+        self.buckets = None    # the GradientBuckets that reduce this buffer (data-parallel runs)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -108,9 +110,12 @@ class GradientBuckets:
         self.bucket_of = {}
         self.pending0 = []
         self.slices = []
-        self.issued_early = 0     # buckets reduced from a gradient hook, i.e. while backward was still running
+        self.issued_early = 0     # buckets reduced while backward was still being queued (hook or trunk executor)
+        self.transport = None
         if not self.active:
             return
+        from .comm import transport
+        self.transport = transport(group)
         if own_communicator is None:
             import os
             own_communicator = os.environ.get("LIDOG_GRAD_COMM", "shared") == "own"
@@ -128,10 +133,14 @@ class GradientBuckets:
                 members, count, cur_hi = [], 0, cur_lo
         if members:
             self._close(members, cur_lo, cur_hi, count)
-        self.pending = list(self.pending0)
+        # countdown per bucket, shared with the trunk executor (csrc/trunk.hip counts the trunk's parameters down in C
+        # and reduces a bucket itself when it reaches 0): a host int32 array, not a list
+        self.pending = np.array(self.pending0, dtype=np.int32)
+        self.slice_table = np.array(self.slices, dtype=np.int64).reshape(-1, 2)
         for p in flat.params:
             p.register_post_accumulate_grad_hook(self._hook)
-        flat.hooked = True     # gradients must reach .grad through autograd (lidog_amd.trunk binds them by hand otherwise)
+        flat.hooked = True     # parameters outside the trunk executor reach their bucket through these hooks
+        flat.buckets = self
 
     def _close(self, members, lo, hi, count):
         b = len(self.slices)
@@ -156,6 +165,15 @@ class GradientBuckets:
         lo, hi = self.slices[b]
         buf = self.flat.grad[lo:hi]
         lane = ME.wgrad_lane(buf.device) if buf.is_cuda else None
+        tr = self.transport
+        if tr.kind == "native":
+            # on the bucket stream, behind what the compute stream and the weight-gradient stream hold now; nothing
+            # waits for it before finish()
+            tr.stream.wait_stream(torch.cuda.current_stream(buf.device))
+            if lane is not None:
+                tr.stream.wait_stream(lane.stream)
+            call_on(tr.raw_stream, "lidog_allreduce_f32", ptr(buf), hi - lo, tr.comm_grad)
+            return
         if lane is not None:
             main = torch.cuda.current_stream(buf.device)
             lane.stream.wait_stream(main)          # BatchNorm / bias gradients of the bucket are written on main
@@ -168,13 +186,25 @@ class GradientBuckets:
         """wait for every bucket; buckets whose hooks did not all fire (unused parameters) are reduced now"""
         if not self.active:
             return
-        for b, left in enumerate(self.pending):
+        for b, left in enumerate(self.pending.tolist()):
             if left > 0:
                 self._reduce(b)
         for h in self.handles:
             h.wait()
         self.handles = []
-        self.pending = list(self.pending0)
+        if self.transport.kind == "native":
+            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.transport.stream)
+        self.pending[:] = self.pending0
+
+    def executor_tables(self, params_by_slot):
+        """int32 [n, 4] bucket of each (kernel, bias, BatchNorm weight, BatchNorm bias) of the trunk's convolutions,
+        -1 where a convolution has no such parameter (lidog_trunk_backward, dp[9])"""
+        out = np.full((len(params_by_slot), 4), -1, dtype=np.int32)
+        for ci, slot in enumerate(params_by_slot):
+            for j, p in enumerate(slot):
+                if p is not None:
+                    out[ci, j] = self.bucket_of[id(p)]
+        return out
 
 
 class TransposedKernels:

@@ -6,10 +6,13 @@ per step.  The launch sequence is static, so it is written down ONCE per model a
 by `lidog_trunk_forward` / `lidog_trunk_backward` -- the same entry points in the same order with the same
 arguments, hence bit-identical results (tests/test_gpu_trunk.py) -- behind a single `torch.autograd.Function`.
 
-The executor takes the training step of a model whose trunk is built from the modules of lidog_amd.me with local
-BatchNorm statistics.  Everything else (evaluation mode, no_grad, SyncBatchNorm with a process group, frozen
-parameters, LIDOG_TRUNK_EXEC=0) stays on the operator path.
+The executor takes the training step of a model whose trunk is built from the modules of lidog_amd.me, with local
+BatchNorm statistics or -- a data-parallel rank (train_lidog.py:227-231) -- with SyncBatchNorm over ONE process group
+and the optimiser's gradient buckets: the statistics all-reduces and the bucket all-reduces are then issued from C
+(lidog_amd.comm).  Everything else (evaluation mode, no_grad, frozen parameters, LIDOG_TRUNK_EXEC=0) stays on the
+operator path.
 """
+import ctypes
 import os
 import weakref
 
@@ -36,6 +39,12 @@ def set_enabled(on):
     """trunk executor on / off (off: every step goes through the operator path)"""
     global ENABLED
     ENABLED = bool(on)
+
+
+def set_fusions(mask):
+    """which fusions the executor applies on top of the operator path's launch sequence (lidog_trunk_fusions; bit 1 =
+    BatchNorm-backward statistics inside the producing data-gradient reduction); returns the previous mask"""
+    return _lib.load().lidog_trunk_fusions(int(mask))
 
 
 class _Unsupported(Exception):
@@ -235,10 +244,11 @@ def _eligible(model, prog, x):
         return False
     if ME._CENTER_FUSED:
         return False
+    group = prog.bns[0]._sync_group() if prog.bns else None
     for bnm in prog.bns:
         bn = bnm.bn
         if not (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None) or \
-                bnm._sync_group() is not None:
+                bnm._sync_group() is not group:
             return False
     for p in prog.params:
         if not p.requires_grad or p.dtype != torch.float32 or not p.is_cuda:
@@ -345,6 +355,87 @@ def _build_tables(prog, x, run):
     return run
 
 
+DP_COLS = 12
+(DP_SYNC_BN, DP_COMM_BN, DP_CALLBACK, DP_COMM_GRAD, DP_COMM_STREAM, DP_GRAD_BASE, DP_N_BUCKETS, DP_BUCKETS, DP_PENDING,
+ DP_PARAM_BUCKET) = range(10)
+_CALLBACK_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64)
+
+
+class _Collectives:
+    """The `dp` argument of lidog_trunk_forward / _backward for one pass (include/lidog_amd.h): SyncBatchNorm statistics
+    over `group` (None = local statistics) and/or the gradient buckets of the optimiser that owns the trunk's
+    parameters.  Native transport: communicator handles; torch transport: a host callback into torch.distributed."""
+
+    def __init__(self, run, group):
+        from .comm import transport
+        self.run, self.group = run, group
+        self.error = None
+        self.tr = transport(group) if group is not None else None
+        self.desc = np.zeros(DP_COLS, dtype=np.int64)
+        self.cb = _CALLBACK_T(self._callback)     # kept alive with the run
+        self.desc[DP_CALLBACK] = ctypes.cast(self.cb, ctypes.c_void_p).value
+        if self.tr is not None:
+            self.desc[DP_SYNC_BN] = 1
+            if self.tr.kind == "native":
+                self.desc[DP_COMM_BN] = self.tr.comm_bn
+        self.scratch = None       # the tensor the statistics messages live in (set per call)
+        self.buckets = None
+
+    def use_buckets(self, buckets, prog):
+        """hand the countdown of the gradient buckets to C for this backward pass"""
+        tr = buckets.transport
+        self.buckets = buckets
+        d = self.desc
+        cached = prog.__dict__.get("_param_bucket")
+        if cached is None or cached[0] is not buckets:
+            by_slot = [[prog.params[s] if s >= 0 else None for s in slot] for slot in prog.slots]
+            cached = prog._param_bucket = (buckets, buckets.executor_tables(by_slot))
+        self.param_bucket = cached[1]
+        d[DP_N_BUCKETS] = len(buckets.slices)
+        d[DP_BUCKETS] = buckets.slice_table.ctypes.data
+        d[DP_PENDING] = buckets.pending.ctypes.data
+        d[DP_PARAM_BUCKET] = self.param_bucket.ctypes.data
+        if tr.kind == "native":
+            d[DP_COMM_GRAD], d[DP_COMM_STREAM] = tr.comm_grad, tr.raw_stream
+            d[DP_GRAD_BASE] = buckets.flat.grad.data_ptr()
+        else:
+            d[DP_COMM_GRAD] = d[DP_COMM_STREAM] = d[DP_GRAD_BASE] = 0
+
+    def no_buckets(self):
+        self.buckets = None
+        self.desc[DP_N_BUCKETS] = 0
+
+    def _callback(self, what, a, b):
+        try:
+            if what == 0:    # all-reduce of b doubles at device address a (inside the scratch region of this call)
+                off = a - self.scratch.data_ptr()
+                if off < 0 or off + 8 * b > self.scratch.numel():
+                    raise RuntimeError("statistics message outside the scratch region")
+                self.tr.allreduce_f64(self.scratch[off:off + 8 * b].view(torch.float64))
+            elif what == 1:
+                # the bucket's weight gradients may still be running on the lane stream: mark it busy so that the
+                # reduction is ordered behind it (GradientBuckets._reduce), until the optimiser's join
+                dev = self.buckets.flat.grad.device
+                if ME._WgradLane.active():
+                    ME._WgradLane.get(dev).pending = True
+                self.buckets.issued_early += 1
+                self.buckets._reduce(int(a))
+            else:
+                raise RuntimeError(f"unknown collective request {what}")
+            return 0
+        except BaseException as exc:   # noqa: BLE001 -- must not propagate through the C frames
+            self.error = exc
+            return 1
+
+    def ptr(self):
+        return self.desc.ctypes.data
+
+    def check(self):
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise err
+
+
 class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, run, *params):
@@ -359,7 +450,9 @@ class _TrunkFn(torch.autograd.Function):
         args = (run.convs.ctypes.data, run.conv_f.ctypes.data, len(prog.convs), run.maps.ctypes.data, len(run.maps),
                 prog.ops.ctypes.data, len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs), run.levels.ctypes.data,
                 run.ext.ctypes.data)
-        call("lidog_trunk_forward", *args, None, 0, None, 0, run.rec.ctypes.data, need.ctypes.data, 1)
+        coll = run.coll
+        dp = coll.ptr() if coll is not None else None
+        call("lidog_trunk_forward", *args, None, 0, None, 0, run.rec.ctypes.data, need.ctypes.data, 1, dp)
         arenas = run.arenas
         owner = arenas.fwd_owner() if arenas.fwd_owner is not None else None
         if owner is not None and not owner.done:
@@ -369,8 +462,15 @@ class _TrunkFn(torch.autograd.Function):
             arena = arenas.get("fwd", int(need[0]), dev)
             arenas.fwd_owner = weakref.ref(run)
         scratch = arenas.get("scratch", int(need[1]), dev)
-        call("lidog_trunk_forward", *args, arena.data_ptr(), arena.numel(), scratch.data_ptr(), scratch.numel(),
-             run.rec.ctypes.data, need.ctypes.data, 0)
+        if coll is not None:
+            coll.scratch = scratch
+        try:
+            call("lidog_trunk_forward", *args, arena.data_ptr(), arena.numel(), scratch.data_ptr(), scratch.numel(),
+                 run.rec.ctypes.data, need.ctypes.data, 0, dp)
+        except RuntimeError:
+            if coll is not None:
+                coll.check()
+            raise
         run.args, run.arena = args, arena
         ctx.run = run
         ctx.set_materialize_grads(False)
@@ -430,23 +530,45 @@ class _TrunkFn(torch.autograd.Function):
         lane = ME._WgradLane.get(dev) if ME._WgradLane.active() else None
         need = np.zeros(3, dtype=np.int64)
         done = np.zeros(len(prog.convs), dtype=np.int32)
+        # Data-parallel gradient buckets (lidog_amd.optim.GradientBuckets): with every gradient going straight into the
+        # flat buffer the countdown of the trunk's parameters runs in C and a bucket is reduced as soon as its last
+        # gradient is queued; otherwise the gradients go back through autograd and the parameters' hooks count.
+        buckets = flat[0].buckets if (direct and flat[0].buckets is not None and flat[0].buckets.active) else None
+        coll = run.coll
+        if buckets is not None and coll is None:
+            coll = run.coll = _Collectives(run, None)
+        if coll is not None:
+            if buckets is not None:
+                coll.use_buckets(buckets, prog)
+            else:
+                coll.no_buckets()
+        dp = (coll.ptr() if coll is not None else None,)
         args = run.args + (ext_grad.ctypes.data, run.arena.data_ptr(), run.rec.ctypes.data)
         tail = (need.ctypes.data, done.ctypes.data)
         mode = (1 if (lane is not None and ME._WgradLane.mode == 1) else 0,)
         lane_raw = lane.raw if lane is not None else None
-        call_on(lane_raw, "lidog_trunk_backward", *args, None, 0, None, 0, None, 0, *tail, 1, *mode, _lib.stream())
+        call_on(lane_raw, "lidog_trunk_backward", *args, None, 0, None, 0, None, 0, *tail, 1, *mode, *dp, _lib.stream())
         arenas = run.arenas
         garena = arenas.get("grad", int(need[0]), dev)
         scratch = arenas.get("scratch", int(need[1]), dev)
         lscratch = arenas.get("lane", max(int(need[2]), 256), dev)
-        call_on(lane_raw, "lidog_trunk_backward", *args, garena.data_ptr(), garena.numel(), scratch.data_ptr(),
-                scratch.numel(), lscratch.data_ptr(), lscratch.numel(), *tail, 0, *mode, _lib.stream())
+        if coll is not None:
+            coll.scratch = scratch
+        open_before = buckets.pending > 0 if buckets is not None else None
+        try:
+            call_on(lane_raw, "lidog_trunk_backward", *args, garena.data_ptr(), garena.numel(), scratch.data_ptr(),
+                    scratch.numel(), lscratch.data_ptr(), lscratch.numel(), *tail, 0, *mode, *dp, _lib.stream())
+        except RuntimeError:
+            if coll is not None:
+                coll.check()
+            raise
+        if buckets is not None and buckets.transport.kind == "native":
+            buckets.issued_early += int((open_before & (buckets.pending == 0)).sum())
         run.done = True
         grads = [None] * len(prog.params)
         params = prog.params
-        # gradient hooks on the parameters (the data-parallel buckets of lidog_amd.optim.GradientBuckets): the gradients
-        # go back through autograd so that the hooks fire
-        bind = direct and not flat[0].hooked
+        # without bucket tables in C the gradients of a hooked optimiser go back through autograd so that the hooks fire
+        bind = direct and (buckets is not None or not flat[0].hooked)
         for ci, slot in enumerate(prog.slots):
             if done[ci]:
                 for s in slot:
@@ -466,8 +588,10 @@ def trunk_forward(model, x):
         return None
     run = _Run()
     run.prog, run.arenas = prog, model.__dict__["_lidog_trunk_arenas"]
+    group = prog.bns[0]._sync_group() if prog.bns else None
     if _build_tables(prog, x, run) is None:
         return None
+    run.coll = _Collectives(run, group) if group is not None else None
     cm = x.coordinate_manager
     cm.trace.extend(prog.trace)
     feats = x.F.contiguous()

@@ -137,3 +137,86 @@ def test_rccl_collectives_through_the_c_abi():
     ok = q.get(timeout=300)
     p.join(60)
     assert p.exitcode == 0 and ok
+
+
+def _rccl_executor_worker(q, port):
+    """own process, ONE-rank RCCL group, every data-parallel path on: the trunk executor with its collectives issued
+    from C on this library's communicators against the operator path -- same bits"""
+    import traceback
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        sys.path.insert(0, REPO)
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import lidog_amd
+        import lidog_amd.me as ME
+        from helpers import seeded_state_dict, small_batch
+        from lidog_amd import comm, trunk
+        from lidog_amd.optim import FlatAdam, GradientBuckets
+        from lidog_amd.trainer import LiDOGStep, setup_data_parallel
+        ME.MinkowskiSyncBatchNorm.single_rank = GradientBuckets.single_rank = True
+
+        def batch(seeds):
+            coords = small_batch(seeds, n_points=2500).cuda()
+            g = torch.Generator().manual_seed(seeds[0])
+            n = coords.shape[0]
+            return {"coords_int": coords, "source_features0": torch.ones((n, 1), device="cuda"),
+                    "source_sem_labels0": torch.randint(-1, 7, (n,), generator=g).cuda(),
+                    "source_bev_labels0": {"block8": torch.randint(-1, 7, (len(seeds), 17, 17), generator=g).cuda()}}
+
+        runs = {}
+        for on in (False, True):
+            trunk.set_enabled(on)
+            model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=5.0).cuda()
+            model.load_state_dict(seeded_state_dict(model, 5))
+            model = setup_data_parallel(model).train()
+            assert sum(isinstance(m, ME.MinkowskiSyncBatchNorm) for m in model.modules()) == 62
+            opt = FlatAdam(model, lr=1e-2, weight_decay=1e-4, bucket_bytes=8 << 20)
+            assert opt.buckets.active and opt.buckets.transport.kind == "native" and comm.transport().comm_bn
+            step = LiDOGStep(model, opt)
+            losses, grads, took = [], [], []
+            for it in range(3):
+                b = batch((61 + it, 71 + it))
+                total, sem_l, bev_l, sem = step.forward_loss(b)
+                took.append(type(sem.F.grad_fn).__name__)
+                opt.zero_grad()
+                total.backward()
+                opt.step()
+                torch.cuda.synchronize()
+                assert opt.strays == 0
+                losses.append([float(total.detach()), float(sem_l.detach()), float(bev_l.detach())])
+                grads.append(opt.flat.grad.clone())
+            assert all((t == "_TrunkFnBackward") == on for t in took), took
+            assert opt.buckets.issued_early >= 3
+            runs[on] = (losses, grads, {k: v.clone() for k, v in model.state_dict().items()})
+        ok, msg = True, ""
+        if runs[True][0] != runs[False][0]:
+            ok, msg = False, f"losses {runs[True][0]} vs {runs[False][0]}"
+        for i, (a, b) in enumerate(zip(runs[True][1], runs[False][1])):
+            if not torch.equal(a, b):
+                ok, msg = False, msg + f" gradients of step {i} differ by {(a - b).abs().max().item():.3e}"
+        for k in runs[True][2]:
+            if not torch.equal(runs[True][2][k], runs[False][2][k]):
+                ok, msg = False, msg + f" state {k} differs"
+                break
+        q.put((ok, msg))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((False, f"{e!r}\n{traceback.format_exc()}"))
+        raise
+
+
+def test_executor_with_rccl_collectives_equals_the_operator_path():
+    """A data-parallel rank runs the trunk executor: SyncBatchNorm statistics all-reduced on the compute stream
+    through lidog_allreduce_f64 from inside lidog_trunk_forward / _backward, gradient buckets reduced from C as their
+    last gradient is queued -- against real RCCL (one rank), bit-identical to the operator path's SyncBatchNorm step
+    over three optimiser steps (losses, reduced gradients, parameters, running statistics)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_executor_worker, args=(q, 29500 + os.getpid() % 2000))
+    p.start()
+    ok, msg = q.get(timeout=600)
+    p.join(120)
+    assert ok, msg
+    assert p.exitcode == 0

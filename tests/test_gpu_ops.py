@@ -323,3 +323,47 @@ def test_output_stationary_conv_equals_two_pass_and_oracle(Cin, Cout, n):
     call("lidog_sconv_os", ptr(gy.cuda()), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, N, ptr(Wt), 1, Cout, Cin,
          ptr(gx), None)
     assert torch.equal(gx.cpu(), xo.grad)
+
+
+@pytest.mark.parametrize("C,mask", [(96, "from_x"), (96, "from_y"), (32, "none"), (256, "from_y")])
+def test_reduction_with_batchnorm_backward_statistics_in_its_epilogue(C, mask):
+    """lidog_sconv_reduce_rows_bwdstats == lidog_sconv_reduce_rows followed by lidog_bn_bwd_reduce on its output: the
+    gradient rows, the fp64 sums, the row count behind them and the parameter gradients, bit for bit"""
+    import lidog_amd.me as ME
+    from lidog_amd._lib import call, load, ptr
+    coords = _rand_coords(9, n=30000, extent=24)
+    _, sg = _maps(coords)
+    m = sg.coordinate_manager.kernel_map(1, 1, 3)
+    n = m.n_in
+    g = torch.Generator(device="cuda").manual_seed(C)
+    T = torch.randn(m.P, C, device="cuda", generator=g)
+    addend = torch.randn(n, C, device="cuda", generator=g)
+    pre = torch.randn(n, C, device="cuda", generator=g) * 2 + 0.5
+    mean = torch.randn(C, device="cuda", generator=g) * 0.1 + 0.5
+    invstd = torch.rand(C, device="cuda", generator=g) + 0.5
+    w = torch.rand(C, device="cuda", generator=g) + 0.5
+    b = torch.randn(C, device="cuda", generator=g) * 0.3
+    y = torch.relu((pre - mean) * invstd * w + b + torch.randn(n, C, device="cuda", generator=g))
+    rp, rl = m.rows("in")
+    L = load()
+    ws = torch.empty(L.lidog_bn_reduce_ws(C, 1), dtype=torch.float64, device="cuda")
+    ry, rw, rb = (y, None, None) if mask == "from_y" else (None, w, b) if mask == "from_x" else (None, None, None)
+    for add in (addend, None):
+        out_a, out_b = torch.empty(n, C, device="cuda"), torch.empty(n, C, device="cuda")
+        sums_a = torch.full((2 * C + 1,), -1.0, dtype=torch.float64, device="cuda")
+        sums_b = sums_a.clone()
+        dw_a, db_a, dw_b, db_b = (torch.empty(C, device="cuda") for _ in range(4))
+        call("lidog_sconv_reduce_rows", ptr(T), ptr(rp), ptr(rl), n, C, None, ptr(add), ptr(out_a))
+        call("lidog_bn_bwd_reduce", ptr(out_a), ptr(pre), ptr(ry), n, C, 1, ptr(mean), ptr(invstd), ptr(sums_a), ptr(ws),
+             float(n), ptr(dw_a), ptr(db_a), ptr(rw), ptr(rb))
+        call("lidog_sconv_reduce_rows_bwdstats", ptr(T), ptr(rp), ptr(rl), n, C, ptr(add), ptr(out_b), ptr(pre), ptr(ry),
+             ptr(mean), ptr(invstd), ptr(rw), ptr(rb), ptr(sums_b), ptr(ws), float(n), ptr(dw_b), ptr(db_b))
+        assert torch.equal(out_a, out_b)
+        assert torch.equal(sums_a, sums_b) and float(sums_b[2 * C]) == n
+        assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+        # and the sums are what they should be (float64 reference)
+        gm = out_a.double() * ((y > 0) if mask == "from_y" else ((pre - mean) * invstd * w + b > 0) if mask == "from_x"
+                               else torch.ones_like(y, dtype=torch.bool))
+        xh = ((pre - mean) * invstd).double()
+        ref = torch.cat([gm.sum(0), (gm * xh).sum(0)])
+        torch.testing.assert_close(sums_b[:2 * C], ref, rtol=1e-9, atol=1e-7)

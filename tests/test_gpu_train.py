@@ -211,16 +211,16 @@ def test_model_called_twice_before_one_backward():
 
 
 # ------------------------------------------------------------------ two data-parallel ranks == one rank, joint batch
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, executor=True):
     try:
-        _dp_worker_body(rank, world, port, q)
+        _dp_worker_body(rank, world, port, q, executor)
     except Exception as e:   # report instead of dying silently: the peer would sit in its barrier until the timeout
         import traceback
         q.put((rank, False, f"{e!r}\n{traceback.format_exc()}"))
         raise
 
 
-def _dp_worker_body(rank, world, port, q):
+def _dp_worker_body(rank, world, port, q, executor):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, REPO)
@@ -232,6 +232,8 @@ def _dp_worker_body(rank, world, port, q):
     from lidog_amd.losses import DICELoss, SoftDICELoss
     from lidog_amd.optim import FlatAdam
     from lidog_amd.trainer import LiDOGStep, setup_data_parallel
+    from lidog_amd import trunk
+    trunk.set_enabled(executor)
     kw = dict(in_channels=1, out_channels=7, D=3, decoder_2d_level=["block8"], mapping_bound_2d=5.0)
     torch.manual_seed(100 + rank)          # ranks seed differently: the start-up broadcast must align them
     model = lidog_amd.MinkUNet34BEV(**kw)
@@ -246,10 +248,17 @@ def _dp_worker_body(rank, world, port, q):
     data = _Scenes(2, seed0=70, n_points=1500)
     mine = data.batch([rank], "cuda")
     total, sem_l, bev_l, sem = step.forward_loss(mine)
+    # a data-parallel rank (SyncBatchNorm + gradient buckets) runs the trunk executor, its collectives issued from C
+    # (here through the host callback into torch.distributed: gloo), unless the executor is switched off
+    took = type(sem.F.grad_fn).__name__
+    assert (took == "_TrunkFnBackward") == executor, took
     opt.zero_grad()
     total.backward()
     opt._prepare()                           # joins the lane, waits for the buckets: flat.grad = SUM over ranks
     torch.cuda.synchronize()
+    assert opt.strays == 0                   # every gradient was written in place (no copy into the flat buffer)
+    base = opt.flat.grad.data_ptr()
+    assert all(p.grad is not None and p.grad.data_ptr() == base + 4 * off for p, off in zip(opt.flat.params, opt.flat.offsets))
     g_dp = opt.flat.grad / world
     early = opt.buckets.issued_early
     losses = torch.tensor([float(total.detach())], dtype=torch.float64)
@@ -303,11 +312,12 @@ def _dp_worker_body(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_lidog_step_two_ranks_equal_one_rank_on_the_joint_batch():
+@pytest.mark.parametrize("executor", [True, False], ids=["trunk_executor", "operator_path"])
+def test_lidog_step_two_ranks_equal_one_rank_on_the_joint_batch(executor):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29800 + os.getpid() % 2000 + (0 if executor else 7)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, executor)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]

@@ -45,13 +45,16 @@ def _assert_same(a, b, what):
             assert torch.equal(a[k], b[k]), f"{what} {k}: max |diff| {(a[k] - b[k]).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("fusions", [1, 0], ids=["fused", "plain_sequence"])
 @pytest.mark.parametrize("overlap", [True, False])
-def test_executor_step_is_bit_identical_to_the_operator_path(overlap):
-    """3 optimiser steps of the LiDOG step (Adam on flat buffers), executor on vs off"""
+def test_executor_step_is_bit_identical_to_the_operator_path(overlap, fusions):
+    """3 optimiser steps of the LiDOG step (Adam on flat buffers), executor on vs off; with the executor's fusions
+    (BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction) and without them"""
     from lidog_amd import me as ME, trunk
     from lidog_amd.trainer import LiDOGStep
     from lidog_amd.optim import make_optimizer
     ME.set_backward_overlap(overlap)
+    before = trunk.set_fusions(fusions)
     try:
         runs = {}
         for on in (False, True):
@@ -71,6 +74,7 @@ def test_executor_step_is_bit_identical_to_the_operator_path(overlap):
         _assert_same(runs[True][2], runs[False][2], "state after 3 steps")
     finally:
         trunk.set_enabled(True)
+        trunk.set_fusions(before)
         ME.set_backward_overlap(True)
 
 
@@ -276,6 +280,12 @@ def _dp_plain_worker(rank, world, port, q):
         sem.F.square().mean().backward()
         opt._prepare()
         torch.cuda.synchronize()
+        # the buckets were counted down and reduced from C while backward was being queued; every gradient sits in
+        # place in the flat buffer (no AccumulateGrad clone, no stray copy)
+        assert opt.buckets.issued_early >= 1 and opt.strays == 0
+        base = opt.flat.grad.data_ptr()
+        for p, off in zip(opt.flat.params, opt.flat.offsets):
+            assert p.grad is None or p.grad.data_ptr() == base + 4 * off
         got = opt.flat.grad.clone()
         # (b) operator path, no data parallelism, summed by hand
         trunk.set_enabled(False)
@@ -299,8 +309,8 @@ def _dp_plain_worker(rank, world, port, q):
 
 
 def test_executor_under_plain_data_parallel_fires_the_gradient_hooks():
-    """DDP without SyncBatchNorm (local statistics): the executor runs, its gradients go through autograd so that the
-    bucket hooks reduce them: flat gradient == sum over ranks of the operator path's local gradients, bit for bit"""
+    """DDP without SyncBatchNorm (local statistics): the executor runs and counts the gradient buckets down itself
+    (lidog_trunk_backward, dp tables): flat gradient == sum over ranks of the operator path's local gradients, bit for bit"""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -77,11 +77,12 @@ def _dry(prog, levels, ext_grad, lane=True):
     done = np.zeros(len(convs), np.int32)
     common = (convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps), prog.ops.ctypes.data,
               len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs), lv.ctypes.data, ext.ctypes.data)
-    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need_f.ctypes.data, 1, None)
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need_f.ctypes.data, 1, None, None)
     assert rc == 0, L.lidog_last_error()
     eg = np.array(ext_grad, np.int64)
     rc = L.lidog_trunk_backward(*common, eg.ctypes.data, None, rec.ctypes.data, None, 0, None, 0, None, 0,
-                                need_b.ctypes.data, done.ctypes.data, 1, 0, None, ctypes.c_void_p(4096 if lane else 0))
+                                need_b.ctypes.data, done.ctypes.data, 1, 0, None, None,
+                                ctypes.c_void_p(4096 if lane else 0))
     assert rc == 0, L.lidog_last_error()
     return need_f, need_b, done, common, (rec, lv, maps, convs, conv_f, ext)   # the arrays `common` points into
 
@@ -108,6 +109,32 @@ def test_dry_run_plans_memory_and_gradient_reach(prog):
     assert not done.any()
 
 
+def test_data_parallel_descriptor_is_checked_and_planned(prog):
+    """dp argument of the executor (include/lidog_amd.h): SyncBatchNorm without a communicator or callback, and bucket
+    tables without a transport, are refused; a dry run with SyncBatchNorm on plans the same regions (the joint
+    conv1 + downsample message lives in the scratch region)"""
+    from lidog_amd import _lib
+    L = _lib.load()
+    levels = [20000, 12000, 6000, 2500, 900]
+    need_f, need_b, _, common, keep = _dry(prog, levels, [0, 4096, 4096, 0, 0, 0, 0])
+    rec, need = np.zeros(prog.n_rec, np.int64), np.zeros(2, np.int64)
+    dp = np.zeros(12, np.int64)
+    dp[0] = 1
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1, dp.ctypes.data, None)
+    assert rc != 0 and b"communicator or a callback" in L.lidog_last_error()
+    dp[2] = 4096       # a callback address: never called in a dry run
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1, dp.ctypes.data, None)
+    assert rc == 0, L.lidog_last_error()
+    assert need[0] == need_f[0] and need_f[1] <= need[1] <= 1.1 * need_f[1]   # conv1 and the downsample share one pass
+    dp2 = np.zeros(12, np.int64)
+    dp2[6] = 3
+    need3, done = np.zeros(3, np.int64), np.zeros(len(prog.convs), np.int32)
+    eg = np.array([0, 4096, 4096, 0, 0, 0, 0], np.int64)
+    rc = L.lidog_trunk_backward(*common, eg.ctypes.data, None, rec.ctypes.data, None, 0, None, 0, None, 0,
+                                need3.ctypes.data, done.ctypes.data, 1, 0, dp2.ctypes.data, None, None)
+    assert rc != 0 and b"bucket tables" in L.lidog_last_error()
+
+
 def test_real_run_refuses_regions_that_are_too_small(prog):
     from lidog_amd import _lib
     L = _lib.load()
@@ -117,7 +144,7 @@ def test_real_run_refuses_regions_that_are_too_small(prog):
     need = np.zeros(2, np.int64)
     # one byte short of the plan: refused before anything is launched (no GPU is touched on this path)
     rc = L.lidog_trunk_forward(*common, ctypes.c_void_p(4096), int(need_f[0]) - 1, ctypes.c_void_p(4096), int(need_f[1]),
-                               rec.ctypes.data, need.ctypes.data, 0, None)
+                               rec.ctypes.data, need.ctypes.data, 0, None, None)
     assert rc != 0 and b"arena" in L.lidog_last_error()
 
 
@@ -133,7 +160,7 @@ def test_tables_are_checked(prog):
     rc = L.lidog_trunk_forward(convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps),
                                prog.ops.ctypes.data, len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs),
                                lv.ctypes.data, ext.ctypes.data, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1,
-                               None)
+                               None, None)
     assert rc != 0 and b"rows" in L.lidog_last_error()
 
 
