@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="build coordinate maps inside the forward pass")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=5.0,
+                    help="repeat the timed block of --steps steps until this much step time is measured; the median block is reported")
+    ap.add_argument("--max-blocks", type=int, default=9)
     return ap.parse_args()
 
 
@@ -100,7 +103,7 @@ class GemmTimer:
         return dict(launches=n, total_ms=ms, bytes=by, flops=fl)
 
 
-def cpu_baseline(config, steps_budget_s=30.0, threads=None):
+def cpu_baseline(config, steps_budget_s=20.0, threads=None):
     """The CPU oracle (ME-equivalent restatement, per-offset gather -> BLAS GEMM -> scatter-add) timed on
     this box's host cores on ONE scan of the same workload, full training step."""
     import oracle.me_cpu as OME
@@ -120,10 +123,9 @@ def cpu_baseline(config, steps_budget_s=30.0, threads=None):
                               mapping_bound_2d=50.0)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    b = synth.make_batch([0], config, device="cpu")
-    t0 = time.time()
-    n = 0
-    while True:
+    scans = [synth.make_batch([seed], config, device="cpu") for seed in (0, 1, 2)]
+
+    def one_step(b):
         st = OME.SparseTensor(coordinates=b["coords_int"], features=b["source_features0"])
         sem, bev = model(st, is_train=True)
         loss = 0.5 * soft_dice_loss_ref(sem.F, b["source_sem_labels0"]) + \
@@ -131,16 +133,25 @@ def cpu_baseline(config, steps_budget_s=30.0, threads=None):
         opt.zero_grad()
         loss.backward()
         opt.step()
+
+    # the first step pays for allocations and thread-pool start-up: it is run but not timed; then one step per scan on
+    # DIFFERENT scans (seeds 1, 2, 0, ...) until the budget is used, at least two
+    t_warm = time.time()
+    one_step(scans[0])
+    t_warm = time.time() - t_warm
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 + (time.time() - t0) / max(n, 1) < steps_budget_s and n < 6):
+        one_step(scans[(n + 1) % 3])
         n += 1
-        if time.time() - t0 > steps_budget_s or n >= 3:
-            break
     dt = time.time() - t0
     OME.set_mode("exact")
     torch.set_num_threads(prev_threads)
     return {"value": n / dt, "unit": "scans/s", "cores": threads, "host_cpu_count": os.cpu_count(),
             "torch_num_threads": threads, "kind": "port",
-            "sample": f"{n} training step(s) of 1 synthetic {config} scan, MinkUNet34BEV B=50, oracle blas mode "
-                      f"(per-offset gather->GEMM->scatter-add), {dt:.1f} s"}
+            "sample": f"{n} training steps, one per synthetic {config} scan (seeds 1, 2, 0, ...), after one untimed step "
+                      f"({t_warm:.1f} s); MinkUNet34BEV B=50, oracle blas mode (per-offset gather->GEMM->scatter-add), "
+                      f"{dt:.1f} s timed"}
 
 
 def main():
@@ -234,17 +245,37 @@ def main():
     for i in range(args.warmup):
         out = run(i)
     sync()
+    # The timed region is EXACTLY --steps steps between two (barrier + synchronize) brackets, max over ranks.  A block
+    # of 20 steps lasts one second, inside a process whose life is dominated by start-up and the CPU-baseline leg; so
+    # the block is repeated until about --min-seconds of step time have been measured (same count on every rank: it
+    # follows from the all-reduced time of the first block) and the MEDIAN block is the one reported -- every block's
+    # figure is in "blocks_ms_per_step".
     timed_steps = 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        # HIP events around the dominant kernel's launches on every 4th timed step (125 launches each): an event
-        # pair costs a few microseconds of queue time per launch, 0.7 ms per step when every step is instrumented
-        timer.enabled = not args.no_kernel_timing and i % 4 == 0
-        timed_steps += int(timer.enabled)
-        out = run(args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
+    blocks = []
+    step_no = args.warmup
+    n_blocks = 1
+    while len(blocks) < n_blocks:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            # HIP events around the dominant kernel's launches on every 4th timed step (125 launches each): an event
+            # pair costs a few microseconds of queue time per launch, 0.7 ms per step when every step is instrumented
+            timer.enabled = not args.no_kernel_timing and i % 4 == 0
+            timed_steps += int(timer.enabled)
+            out = run(step_no)
+            step_no += 1
+        sync()
+        dt_block = time.perf_counter() - t0
+        timer.enabled = False
+        if world > 1:
+            t = torch.tensor([dt_block], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_block = float(t.item())
+        blocks.append(dt_block)
+        if len(blocks) == 1:
+            n_blocks = max(1, min(args.max_blocks, int(-(-args.min_seconds // dt_block))))
+    ordered = sorted(blocks)
+    dt = ordered[len(ordered) // 2]           # median block (the slower of the middle two for an even count)
+    total_timed_steps = args.steps * len(blocks)
     loss = float(out["loss"])
     eval_rate = None
     if world == 1:
@@ -260,11 +291,6 @@ def main():
             run_eval(batches[i % 2]["coords_int"], batches[i % 2]["source_features0"], batches[(i + 1) % 2]["coords_int"])
         torch.cuda.synchronize()
         eval_rate = n_eval * args.batch / (time.perf_counter() - t1)
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
     if rank == 0:
         value = world * args.batch * args.steps / dt
         res = {"metric": "LiDAR scans/sec, MinkUNet34+BEV training step @120k pts", "value": value, "unit": "scans/s",
@@ -277,7 +303,12 @@ def main():
                           "voxels_per_scan": n_vox, "seed0_stride_counts": seed0_counts,
                           "global_batch": world * args.batch,
                           "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else "")},
-               "loss": loss}
+               "blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in blocks], "loss": loss}
+        if world > 1 or single_dp:
+            from lidog_amd.comm import transport
+            res["config"]["collectives"] = transport().kind     # native = this library's RCCL communicators
+            res["config"]["trunk_path"] = "executor" if getattr(step, "last_path", "") == "_TrunkFnBackward" else \
+                getattr(step, "last_path", "unknown")
         if eval_rate is not None:
             res["forward_only_scans_per_s"] = eval_rate
         s = timer.summary()
@@ -301,7 +332,7 @@ def main():
                                "algorithmic_flops_per_launch": s["flops"] / s["launches"],
                                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
                                "avg_launch_us": 1e3 * s["total_ms"] / s["launches"], "launches": s["launches"],
-                               "share_of_step": s["total_ms"] / max(timed_steps, 1) / (1e3 * dt / args.steps),
+                               "share_of_step": s["total_ms"] / max(timed_steps, 1) / (1e3 * sum(blocks) / total_timed_steps),
                                "instrumented_steps": timed_steps,
                                "hbm_gbs": gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:

@@ -45,6 +45,11 @@ int64_t lidog_hash_capacity(int64_t n);
  * n_unique_dev receives the number of distinct coordinates (device int64). */
 int lidog_coords_insert(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int64_t cap,
                         int32_t *first_row, int64_t *n_unique_dev, int32_t *err_flag, void *stream);
+/* the same, and in the same pass what a caller needs to size occupancy bitmaps and batch loops:
+ * info [9] int64 (device) = (unique rows, error flag, largest batch index, lowest x, y, z, highest x, y, z) -- one
+ * read-back instead of n_unique + err + three device-wide min / max reductions of the caller's own. */
+int lidog_coords_insert_info(const int32_t *coords, int64_t n, uint64_t *keys, int32_t *vals, int64_t cap,
+                             int32_t *first_row, int64_t *info, int32_t *err_flag, void *stream);
 
 /* Compact a map with duplicates: unique_rows[j] = first-occurrence row of output row j (ascending),
  * inverse[i] = output row of input row i; rewrites vals to output rows.  scan_ws: int32[n + 2048]. */

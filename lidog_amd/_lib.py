@@ -17,6 +17,7 @@ SIGNATURES = {
     "lidog_abi_version": [],
     "lidog_hash_capacity": [_i64],
     "lidog_coords_insert": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p],
+    "lidog_coords_insert_info": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p],
     "lidog_coords_compact": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p],
     "lidog_coords_stride": [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p],
     "lidog_kernel_map": [_p, _i64, _p, _p, _i64, _p, _i32, _p, _p],

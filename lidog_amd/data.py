@@ -94,9 +94,11 @@ def label_luts(bound, img_size, voxel, z_range=(-10.0, 8.0)):
 _DEV_LABEL_LUTS = {}
 
 
-def bev_labels(coords, labels, bound=50.0, img_size=167, voxel=0.05):
+def bev_labels(coords, labels, bound=50.0, img_size=167, voxel=0.05, batch_size=None):
     """coords int32 [N,4] (batch, x, y, z) on the GPU, labels [N] -> (img_labels int64 [B,S,S], point_idx int32
-    [B,S,S]) exactly as getBEVImageNew applied scan by scan (ignore label -1 skipped, last point wins)."""
+    [B,S,S]) exactly as getBEVImageNew applied scan by scan (ignore label -1 skipped, last point wins).
+    `batch_size`: number of scans in the batch when the caller knows it (a collate function does): nothing is read
+    back from the device then."""
     _lib.require_gpu(coords, "coordinates")
     dev = coords.device
     key = (float(bound), int(img_size), float(voxel), str(dev))
@@ -107,7 +109,7 @@ def bev_labels(coords, labels, bound=50.0, img_size=167, voxel=0.05):
     lx, ly, lz, lo, S = _DEV_LABEL_LUTS[key]
     coords = coords.contiguous()
     lab = labels.to(torch.int32).contiguous()
-    B = int(coords[:, 0].max().item()) + 1
+    B = int(batch_size) if batch_size is not None else int(coords[:, 0].max().item()) + 1
     counts = torch.bincount(coords[:, 0].long(), minlength=B)
     start = torch.zeros(B + 1, dtype=torch.int64, device=dev)
     start[1:] = torch.cumsum(counts, 0)

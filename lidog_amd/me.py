@@ -412,18 +412,15 @@ class CoordinateManager:
         keys = self._own(torch.empty(cap, dtype=torch.int64, device=self.device))
         vals = self._own(torch.empty(cap, dtype=torch.int32, device=self.device))
         first = torch.empty(n, dtype=torch.int32, device=self.device)
-        n_unique = torch.zeros(1, dtype=torch.int64, device=self.device)
-        call("lidog_coords_insert", ptr(coords), n, ptr(keys), ptr(vals), cap, ptr(first), ptr(n_unique),
+        # unique rows, error flag, largest batch index and the bounding box of the voxels (for the occupancy bitmaps) come
+        # out of the insert kernel itself: ONE read-back, no reduction kernels of torch's on this stream
+        info = torch.empty(9, dtype=torch.int64, device=self.device)
+        call("lidog_coords_insert_info", ptr(coords), n, ptr(keys), ptr(vals), cap, ptr(first), ptr(info),
              ptr(self.err))
-        if n >= _BITMAP_MIN_ROWS and _BITMAPS:   # bounding box of the voxels (for the occupancy bitmaps), in the same read-back
-            lo, hi = coords[:, 1:].amin(0).long(), coords[:, 1:].amax(0).long()
-            stats = torch.cat([torch.stack([n_unique[0], self.err[0].long(), coords[:, 0].max().long()]), lo, hi]).tolist()
-            self.bounds = (tuple(stats[3:6]), tuple(stats[6:9]))
-        else:
-            stats = torch.stack([n_unique[0], self.err[0].long(), coords[:, 0].max().long() if n else n_unique[0]]).tolist()
-            self.bounds = None
+        stats = info.tolist()
+        self.bounds = (tuple(stats[3:6]), tuple(stats[6:9])) if (n >= _BITMAP_MIN_ROWS and _BITMAPS) else None
         if stats[1] != 0:
-            self._check()
+            self._check(1)
         self.batch_size = int(stats[2]) + 1 if n else 0
         uniq = inv = None
         if stats[0] != n:  # duplicates: keep the first occurrence, rows in first-occurrence order

@@ -93,7 +93,8 @@ class LiDOGStep(_CoordinatePrefetch):
     def training_step(self, batch, epoch=0, prefetch=None, prefetch_ready=None):
         """`prefetch`: the batch of the NEXT call (its coordinate maps are built while this step still runs on
         the GPU); `prefetch_ready`: event after which its coordinates are valid (None: everything queued so far)"""
-        total, sem_loss, bev_loss, _ = self.forward_loss(batch, epoch)
+        total, sem_loss, bev_loss, sem = self.forward_loss(batch, epoch)
+        self.last_path = type(sem.F.grad_fn).__name__     # "_TrunkFnBackward": the trunk executor took the pass
         self.opt.zero_grad()
         total.backward()
         self.opt.step()
