@@ -15,10 +15,13 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-# Four HIP streams are busy in a data-parallel step (compute, RCCL, weight gradients, next batch's coordinate
-# maps); with the runtime's default of 4 hardware queues two of them can land on the same queue and serialise
-# (measured: the weight-gradient stream then overlaps nothing).  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Five HIP streams of this library are busy in a data-parallel step (compute, weight gradients, next batch's
+# coordinate maps, gradient buckets, plus torch's and RCCL's internal ones for three communicators); streams that
+# land on the same hardware queue serialise.  Measured on one rank with every collective active: 8 queues 67.7 ms per
+# step (the two extra communicators pushed the weight-gradient stream onto the compute stream's queue), 16 queues
+# 50.7 ms; the runtime's default of 4 already serialised the weight gradients in round 1.  Must be set before the HIP
+# runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # the host driver of this pool only supports dmabuf IPC (RCCL's peer buffers); normally already exported
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 

@@ -37,9 +37,12 @@ class Transport:
             raise ValueError(f"LIDOG_DP_TRANSPORT={want!r}: expected native or torch")
         backend = dist.get_backend(group)
         self.kind = want or ("native" if backend == "nccl" else "torch")
+        # experiment switch: the gradient buckets through torch.distributed while the statistics stay native (or the
+        # other way round with LIDOG_DP_TRANSPORT=torch LIDOG_DP_BUCKETS=native)
+        self.bucket_kind = os.environ.get("LIDOG_DP_BUCKETS", "") or self.kind
         self.comm_bn = self.comm_grad = None
         self.stream = None
-        if self.kind == "native":
+        if "native" in (self.kind, self.bucket_kind):
             if not torch.cuda.is_available():
                 raise RuntimeError("the native RCCL transport needs a GPU")
             self.device = torch.device("cuda", torch.cuda.current_device())

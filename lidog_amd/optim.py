@@ -166,7 +166,7 @@ class GradientBuckets:
         buf = self.flat.grad[lo:hi]
         lane = ME.wgrad_lane(buf.device) if buf.is_cuda else None
         tr = self.transport
-        if tr.kind == "native":
+        if tr.bucket_kind == "native":
             # on the bucket stream, behind what the compute stream and the weight-gradient stream hold now; nothing
             # waits for it before finish()
             tr.stream.wait_stream(torch.cuda.current_stream(buf.device))
@@ -192,7 +192,7 @@ class GradientBuckets:
         for h in self.handles:
             h.wait()
         self.handles = []
-        if self.transport.kind == "native":
+        if self.transport.bucket_kind == "native":
             torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.transport.stream)
         self.pending[:] = self.pending0
 

@@ -378,7 +378,7 @@ class _Collectives:
             self.desc[DP_SYNC_BN] = 1
             if self.tr.kind == "native":
                 self.desc[DP_COMM_BN] = self.tr.comm_bn
-        self.scratch = None       # the tensor the statistics messages live in (set per call)
+        self.regions = ()         # the tensors the statistics messages live in (set per call)
         self.buckets = None
 
     def use_buckets(self, buckets, prog):
@@ -395,7 +395,7 @@ class _Collectives:
         d[DP_BUCKETS] = buckets.slice_table.ctypes.data
         d[DP_PENDING] = buckets.pending.ctypes.data
         d[DP_PARAM_BUCKET] = self.param_bucket.ctypes.data
-        if tr.kind == "native":
+        if tr.bucket_kind == "native":
             d[DP_COMM_GRAD], d[DP_COMM_STREAM] = tr.comm_grad, tr.raw_stream
             d[DP_GRAD_BASE] = buckets.flat.grad.data_ptr()
         else:
@@ -407,11 +407,14 @@ class _Collectives:
 
     def _callback(self, what, a, b):
         try:
-            if what == 0:    # all-reduce of b doubles at device address a (inside the scratch region of this call)
-                off = a - self.scratch.data_ptr()
-                if off < 0 or off + 8 * b > self.scratch.numel():
-                    raise RuntimeError("statistics message outside the scratch region")
-                self.tr.allreduce_f64(self.scratch[off:off + 8 * b].view(torch.float64))
+            if what == 0:    # all-reduce of b doubles at device address a (inside one of the regions of this call)
+                for region in self.regions:
+                    off = a - region.data_ptr()
+                    if 0 <= off and off + 8 * b <= region.numel():
+                        self.tr.allreduce_f64(region[off:off + 8 * b].view(torch.float64))
+                        break
+                else:
+                    raise RuntimeError("statistics message outside the regions of this call")
             elif what == 1:
                 # the bucket's weight gradients may still be running on the lane stream: mark it busy so that the
                 # reduction is ordered behind it (GradientBuckets._reduce), until the optimiser's join
@@ -463,7 +466,7 @@ class _TrunkFn(torch.autograd.Function):
             arenas.fwd_owner = weakref.ref(run)
         scratch = arenas.get("scratch", int(need[1]), dev)
         if coll is not None:
-            coll.scratch = scratch
+            coll.regions = (scratch,)
         try:
             call("lidog_trunk_forward", *args, arena.data_ptr(), arena.numel(), scratch.data_ptr(), scratch.numel(),
                  run.rec.ctypes.data, need.ctypes.data, 0, dp)
@@ -553,7 +556,7 @@ class _TrunkFn(torch.autograd.Function):
         scratch = arenas.get("scratch", int(need[1]), dev)
         lscratch = arenas.get("lane", max(int(need[2]), 256), dev)
         if coll is not None:
-            coll.scratch = scratch
+            coll.regions = (scratch, garena)
         open_before = buckets.pending > 0 if buckets is not None else None
         try:
             call_on(lane_raw, "lidog_trunk_backward", *args, garena.data_ptr(), garena.numel(), scratch.data_ptr(),
@@ -562,7 +565,7 @@ class _TrunkFn(torch.autograd.Function):
             if coll is not None:
                 coll.check()
             raise
-        if buckets is not None and buckets.transport.kind == "native":
+        if buckets is not None and buckets.transport.bucket_kind == "native":
             buckets.issued_early += int((open_before & (buckets.pending == 0)).sum())
         run.done = True
         grads = [None] * len(prog.params)

@@ -4,7 +4,7 @@
 on one GPU:  python scripts/bench_configs.py [steps]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch
 import lidog_amd
 from lidog_amd import synth
