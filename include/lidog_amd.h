@@ -234,6 +234,8 @@ int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float
 /* relu_w / relu_b (both or neither; relu_y must then be NULL; [rows, C] with C % 4 == 0 only): the ReLU mask is
  * recomputed from x with the forward pass's own expression ((x - mean) * invstd * w + b > 0, same bits) instead of
  * being read from the saved output -- for a BatchNorm + ReLU WITHOUT residual, one tensor less to stream. */
+/* upper bound of the workgroups (= rows of fp64 partial sums) of the per-row statistics reductions */
+int32_t lidog_stats_max_blocks(void);
 /* workgroups (= rows of partial sums) lidog_bn_bwd_reduce uses for [n, C] rows, C % 4 == 0 */
 int64_t lidog_bn_bwd_reduce_blocks(int64_t n, int32_t C);
 int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,

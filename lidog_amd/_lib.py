@@ -37,6 +37,7 @@ SIGNATURES = {
     "lidog_sconv_reduce_rows_stats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows_bwdstats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _d, _p, _p, _p],
     "lidog_bn_bwd_reduce_blocks": [_i64, _i32],
+    "lidog_stats_max_blocks": [],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
     "lidog_sconv_os_block_rows": [],
     "lidog_sconv_os_segments": [_p, _p, _i32, _i64, _p, _p],

@@ -470,6 +470,39 @@ __device__ __forceinline__ float4 reduce_row_list(const float4 *__restrict__ T, 
     return acc;
 }
 
+// two rows at once (the statistics kernels below walk several rows per thread: a row's walk is a chain of three
+// dependent loads, and two independent chains in flight halve what a thread waits for); per row the additions are those
+// of reduce_row_list in the same order
+__device__ __forceinline__ void reduce_row_list2(const float4 *__restrict__ T, const int32_t *__restrict__ row_ptr,
+                                                 const int32_t *__restrict__ row_list, int C4, int64_t o0, int64_t o1,
+                                                 int c4, float4 &r0, float4 &r1) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int b0 = row_ptr[o0], e0 = row_ptr[o0 + 1], b1 = row_ptr[o1], e1 = row_ptr[o1 + 1];
+    const int len = (e0 - b0) > (e1 - b1) ? (e0 - b0) : (e1 - b1);
+    for (int q = 0; q < len; q += 4) {
+        int i0[4], i1[4];
+        float4 t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            i0[j] = row_list[b0 + q + j < e0 ? b0 + q + j : (e0 > b0 ? e0 - 1 : 0)];   // an empty row reads entry 0: masked
+            i1[j] = row_list[b1 + q + j < e1 ? b1 + q + j : (e1 > b1 ? e1 - 1 : 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t0[j] = T[(int64_t)i0[j] * C4 + c4];
+            t1[j] = T[(int64_t)i1[j] * C4 + c4];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok0 = b0 + q + j < e0, ok1 = b1 + q + j < e1;
+            a0.x += ok0 ? t0[j].x : 0.f; a0.y += ok0 ? t0[j].y : 0.f; a0.z += ok0 ? t0[j].z : 0.f; a0.w += ok0 ? t0[j].w : 0.f;
+            a1.x += ok1 ? t1[j].x : 0.f; a1.y += ok1 ? t1[j].y : 0.f; a1.z += ok1 ? t1[j].z : 0.f; a1.w += ok1 ? t1[j].w : 0.f;
+        }
+    }
+    r0 = a0;
+    r1 = a1;
+}
+
 __global__ __launch_bounds__(256) void k_sconv_reduce_rows4(const float4 *__restrict__ T,
                                                             const int32_t *__restrict__ row_ptr,
                                                             const int32_t *__restrict__ row_list, int64_t n, int C4,
@@ -509,8 +542,8 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *
     const bool active = r < RB;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
-        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += (int64_t)gridDim.x * RB) {
-            float4 acc = reduce_row_list(T, row_ptr, row_list, C4, o, c4);
+        const int64_t step = (int64_t)gridDim.x * RB;
+        auto emit = [&](int64_t o, float4 acc) {
             if (bias) {
                 float4 b = bias[c4];
                 acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
@@ -519,6 +552,17 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *
             a[0] += acc.x; a[1] += acc.y; a[2] += acc.z; a[3] += acc.w;
             a[4] += (double)acc.x * acc.x; a[5] += (double)acc.y * acc.y;
             a[6] += (double)acc.z * acc.z; a[7] += (double)acc.w * acc.w;
+        };
+        // two rows of this thread in flight (rows o and o + step), accumulated in row order
+        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += 2 * step) {
+            if (o + step < n) {
+                float4 acc0, acc1;
+                reduce_row_list2(T, row_ptr, row_list, C4, o, o + step, c4, acc0, acc1);
+                emit(o, acc0);
+                emit(o + step, acc1);
+            } else {
+                emit(o, reduce_row_list(T, row_ptr, row_list, C4, o, c4));
+            }
         }
     }
 #pragma unroll
@@ -566,16 +610,11 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
 #pragma unroll
             for (int j = 0; j < 4; ++j) { gw[j] = rw[c4 * 4 + j]; gb[j] = rb[c4 * 4 + j]; }
         }
-        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += (int64_t)gridDim.x * RB) {
-            const int64_t idx = o * C4 + c4;
-            const float4 x = pre[idx];
-            float4 y = relu_y ? relu_y[idx] : make_float4(1.f, 1.f, 1.f, 1.f);
-            float4 g = reduce_row_list(T, row_ptr, row_list, C4, o, c4);
-            if (addend) {
-                const float4 ad = addend[idx];
-                g.x += ad.x; g.y += ad.y; g.z += ad.z; g.w += ad.w;
-            }
-            out[idx] = g;
+        const int64_t step = (int64_t)gridDim.x * RB;
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto emit = [&](int64_t idx, float4 g, float4 x, float4 y, float4 ad) {
+            g.x += ad.x; g.y += ad.y; g.z += ad.z; g.w += ad.w;   // no addend: + 0 (a sum of products is never -0 ... and
+            out[idx] = g;                                          // -0 + 0 = +0 compares equal anyway)
             if (from_x) {   // the forward pass's pre-activation, bit for bit (bn.hip:k_bn_apply4)
                 y.x = (x.x - m[0]) * is[0] * gw[0] + gb[0];
                 y.y = (x.y - m[1]) * is[1] * gw[1] + gb[1];
@@ -589,6 +628,25 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
                 const float xh = (xv[j] - m[j]) * is[j];
                 a[j] += (double)gg;
                 a[4 + j] += (double)gg * (double)xh;
+            }
+        };
+        // two rows of this thread in flight (rows o and o + step), accumulated in row order
+        for (int64_t o = (int64_t)blockIdx.x * RB + r; o < n; o += 2 * step) {
+            const int64_t i0 = o * C4 + c4;
+            if (o + step < n) {
+                const int64_t i1 = (o + step) * C4 + c4;
+                const float4 x0 = pre[i0], x1 = pre[i1];
+                const float4 y0 = relu_y ? relu_y[i0] : one, y1 = relu_y ? relu_y[i1] : one;
+                const float4 ad0 = addend ? addend[i0] : zero, ad1 = addend ? addend[i1] : zero;
+                float4 g0, g1;
+                reduce_row_list2(T, row_ptr, row_list, C4, o, o + step, c4, g0, g1);
+                emit(i0, g0, x0, y0, ad0);
+                emit(i1, g1, x1, y1, ad1);
+            } else {
+                const float4 x0 = pre[i0];
+                const float4 y0 = relu_y ? relu_y[i0] : one;
+                const float4 ad0 = addend ? addend[i0] : zero;
+                emit(i0, reduce_row_list(T, row_ptr, row_list, C4, o, c4), x0, y0, ad0);
             }
         }
     }
@@ -710,7 +768,7 @@ extern "C" int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_
 #define RED_STATS_ROWS 1   // rows per thread before the grid-stride loop takes over (A/B switch; was 4)
 #endif
     int64_t nb = cdiv64(n, (int64_t)RB * RED_STATS_ROWS);
-    if (nb > 2048) nb = 2048;
+    if (nb > lidog_stats_max_blocks()) nb = lidog_stats_max_blocks();
     k_sconv_reduce_rows4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, row_ptr, row_list, n, C4,
                                                              (const float4 *)bias, (float4 *)out, partial_ws);
     BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};

@@ -176,11 +176,17 @@ _SIDE_STREAMS = {}
 _EXP_KEPT = {}
 
 
+# stream priorities of the helper streams (HIP: lower number = served first; the step itself runs on torch's current
+# stream): experiments with LIDOG_LANE_PRIORITY / LIDOG_SIDE_PRIORITY
+_LANE_PRIORITY = int(os.environ.get("LIDOG_LANE_PRIORITY", "0"))
+_SIDE_PRIORITY = int(os.environ.get("LIDOG_SIDE_PRIORITY", "0"))
+
+
 def _side_stream(device):
     """the stream coordinate maps are prepared on when they are built ahead of time (CoordinateManager.prepare)"""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key, priority=_SIDE_PRIORITY)
     return _SIDE_STREAMS[key]
 
 
@@ -211,7 +217,7 @@ class _WgradLane:
 
     def __init__(self, device):
         self.device = device
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = torch.cuda.Stream(device=device, priority=_LANE_PRIORITY)
         self.raw = self.stream.cuda_stream    # hipStream_t: kernels are launched on it without switching torch's stream
         self.keep = []
         self.pending = False
