@@ -139,12 +139,13 @@ int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_ptr, const 
  * (ME.MinkowskiBatchNorm backward, minkunet_bev.py:60), `pre` / mean / invstd its saved input and statistics,
  * relu_y or (relu_w, relu_b) its ReLU mask as in lidog_bn_bwd_reduce.  sums / count / dw / db as there; the sums are
  * bit-identical to calling lidog_bn_bwd_reduce on `out` afterwards (same partial sums in the same order), one pass
- * over dy less.  partial_ws: lidog_bn_reduce_ws(C, 1) doubles. */
+ * over dy less.  relu_bits: the mask as written by lidog_bn_apply_bits instead of relu_y.
+ * partial_ws: lidog_bn_reduce_ws(C, 1) doubles. */
 int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n,
                                      int32_t C, const float *addend, float *out, const float *pre,
-                                     const float *relu_y, const float *mean, const float *invstd,
-                                     const float *relu_w, const float *relu_b, double *sums, double *partial_ws,
-                                     double count, float *dw, float *db, void *stream);
+                                     const float *relu_y, const uint32_t *relu_bits, const float *mean,
+                                     const float *invstd, const float *relu_w, const float *relu_b, double *sums,
+                                     double *partial_ws, double count, float *dw, float *db, void *stream);
 /* Validation path (running statistics, minkunet_bev.py:376-393): the reduction with the evaluation-mode BatchNorm
  * (+ residual + ReLU) in its epilogue, same expression and order as lidog_bn_apply. */
 int lidog_sconv_reduce_rows_bn(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n, int32_t C,
@@ -246,6 +247,22 @@ int lidog_bn_bwd_reduce(const float *dy, const float *x, const float *relu_y, in
 int lidog_bn_bwd_apply(const float *dy, const float *x, const float *relu_y, int64_t n, int32_t C, int64_t hw,
                        const float *mean, const float *invstd, const float *w, const double *sums, double count,
                        float *dx, float *dres, float *dw, float *db, const float *relu_b, void *stream);
+/* ReLU masks as bits ([rows, C] with C % 4 == 0; MinkowskiReLU after a residual add, resnet_block.py:8-56): the apply
+ * pass also writes bit 4 * (q % 8) + j of word q / 8 = (element j of float4 number q of y) > 0 into relu_bits
+ * [lidog_relu_bits_words(n, C)], and the two backward passes read that instead of the saved output y (1/32 of the
+ * bytes; same mask, same results).  relu_bits == NULL: exactly the functions above. */
+int64_t lidog_relu_bits_words(int64_t n, int32_t C);
+int lidog_bn_apply_bits(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean, const float *invstd,
+                        const float *w, const float *b, const float *residual, int32_t relu, float *y,
+                        uint32_t *relu_bits, void *stream);
+int lidog_bn_bwd_reduce_bits(const float *dy, const float *x, const float *relu_y, const uint32_t *relu_bits, int64_t n,
+                             int32_t C, int64_t hw, const float *mean, const float *invstd, double *sums, double *ws,
+                             double count, float *dw, float *db, const float *relu_w, const float *relu_b,
+                             void *stream);
+int lidog_bn_bwd_apply_bits(const float *dy, const float *x, const float *relu_y, const uint32_t *relu_bits, int64_t n,
+                            int32_t C, int64_t hw, const float *mean, const float *invstd, const float *w,
+                            const double *sums, double count, float *dx, float *dres, float *dw, float *db,
+                            const float *relu_b, void *stream);
 /* out[c] = sum over the n rows of x[., c] for a narrow matrix (C <= 16; the classifier's bias gradient); ws: 512*C
  * doubles */
 int lidog_colsum(const float *x, int64_t n, int32_t C, float *out, double *ws, void *stream);
@@ -450,7 +467,9 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
                          void *lane);
 /* Fusions the executor applies on top of the operator path's launch sequence (bit mask; results are bit-identical
  * either way): 1 = BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction
- * (lidog_sconv_reduce_rows_bwdstats).  mask >= 0 sets it; returns the previous mask. */
+ * (lidog_sconv_reduce_rows_bwdstats); 2 = the ReLU masks of BatchNorm + residual + ReLU layers kept as bits
+ * (lidog_bn_apply_bits).  mask >= 0 sets it; returns the previous mask.  Set it between passes, not between a forward
+ * pass and its backward pass. */
 int32_t lidog_trunk_fusions(int32_t mask);
 /* Timing of the executor's gathered-GEMM launches for the roofline figure of bench.py: on != 0 brackets every such
  * launch with HIP events on its stream; _read waits for the recorded launches, returns (launches, total ms, algorithmic

@@ -35,7 +35,7 @@ SIGNATURES = {
     "lidog_sconv_reduce_rows": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows_bn": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_sconv_reduce_rows_stats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
-    "lidog_sconv_reduce_rows_bwdstats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _d, _p, _p, _p],
+    "lidog_sconv_reduce_rows_bwdstats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _d, _p, _p, _p],
     "lidog_bn_bwd_reduce_blocks": [_i64, _i32],
     "lidog_stats_max_blocks": [],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
@@ -54,6 +54,10 @@ SIGNATURES = {
     "lidog_bn_apply": [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_bn_bwd_reduce": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
     "lidog_bn_bwd_apply": [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p, _p],
+    "lidog_relu_bits_words": [_i64, _i32],
+    "lidog_bn_apply_bits": [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
+    "lidog_bn_bwd_reduce_bits": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p],
+    "lidog_bn_bwd_apply_bits": [_p, _p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _d, _p, _p, _p, _p, _p, _p],
     "lidog_colsum": [_p, _i64, _i32, _p, _p, _p],
     "lidog_colsum_ws": [_i32],
     "lidog_bn_eval_invstd": [_p, _f, _i32, _p, _p],
@@ -100,7 +104,7 @@ SIGNATURES = {
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
              "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_sconv_center_reduce_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
              "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64, "lidog_bitmap_words": _i64,
-             "lidog_bn_bwd_reduce_blocks": _i64}
+             "lidog_bn_bwd_reduce_blocks": _i64, "lidog_relu_bits_words": _i64}
 
 _lib = None
 

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
                                                        const float *__restrict__ invstd,
                                                        double *__restrict__ partial,
                                                        const float *__restrict__ rw = nullptr,
-                                                       const float *__restrict__ rb = nullptr) {
+                                                       const float *__restrict__ rb = nullptr,
+                                                       const uint32_t *__restrict__ rbits = nullptr) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
     const int tid = threadIdx.x;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
                 if (MODE == 1) {
                     g[u] = dy[row * C4 + c4];
                     y[u] = ry ? ry[row * C4 + c4] : make_float4(1, 1, 1, 1);
+                    if (rbits) y[u] = lidog_relu_bits_as_float4(rbits, row * C4 + c4);
                 } else {
                     g[u] = make_float4(0, 0, 0, 0);
                     y[u] = make_float4(1, 1, 1, 1);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
                     yy.z = (vv.z - m[2]) * is[2] * gw[2] + gb[2];
                     yy.w = (vv.w - m[3]) * is[3] * gw[3] + gb[3];
                 }
-                const bool has_relu = ry != nullptr || from_x;
+                const bool has_relu = ry != nullptr || from_x || rbits != nullptr;
                 red_terms<MODE>(vv.x, gg.x, yy.x, has_relu, m[0], is[0], a[0], a[4]);
                 red_terms<MODE>(vv.y, gg.y, yy.y, has_relu, m[1], is[1], a[1], a[5]);
                 red_terms<MODE>(vv.z, gg.z, yy.z, has_relu, m[2], is[2], a[2], a[6]);
@@ -266,7 +268,8 @@ extern "C" int64_t lidog_bn_bwd_reduce_blocks(int64_t n, int32_t C) {
 template <int MODE>
 static int launch_colreduce(const float *x, const float *dy, const float *ry, int64_t n, int C, int64_t hw,
                             const float *mean, const float *invstd, double *sums, double *ws, double count,
-                            BnFinish fin, hipStream_t st, const float *rw = nullptr, const float *rb = nullptr) {
+                            BnFinish fin, hipStream_t st, const float *rw = nullptr, const float *rb = nullptr,
+                            const uint32_t *rbits = nullptr) {
     if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     if (colreduce_uses_partials(C, hw)) {
         LIDOG_REQUIRE(ws != nullptr, "bn reduce: workspace of lidog_bn_reduce_ws() doubles required");
@@ -280,10 +283,11 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
         if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
         if (MODE == 1) nb = lidog_bn_bwd_reduce_blocks(n, C);
         k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
-                                                            n, C4, mean, invstd, ws, rw, rb);
+                                                            n, C4, mean, invstd, ws, rw, rb, rbits);
         lidog_launch_sums_finish(ws, (int)nb, C, sums, count, fin, st);
     } else {
-        LIDOG_REQUIRE(rw == nullptr, "bn reduce: the ReLU mask can be recomputed from x only for [rows, C] with C %% 4 == 0");
+        LIDOG_REQUIRE(rw == nullptr && rbits == nullptr,
+                      "bn reduce: ReLU masks from x or from a bit mask only for [rows, C] with C %% 4 == 0");
         // atomic variants accumulate: start from zero
         if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) return 1;
         if (hw == 1) {
@@ -321,11 +325,20 @@ extern "C" int lidog_bn_bwd_reduce(const float *dy, const float *x, const float 
                                    int64_t hw, const float *mean, const float *invstd, double *sums, double *ws,
                                    double count, float *dw, float *db, const float *relu_w, const float *relu_b,
                                    void *stream) {
-    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) && !(relu_y && relu_w),
-                  "bn_bwd_reduce: pass either relu_y or (relu_w, relu_b)");
+    return lidog_bn_bwd_reduce_bits(dy, x, relu_y, nullptr, n, C, hw, mean, invstd, sums, ws, count, dw, db, relu_w,
+                                    relu_b, stream);
+}
+
+extern "C" int lidog_bn_bwd_reduce_bits(const float *dy, const float *x, const float *relu_y,
+                                        const uint32_t *relu_bits, int64_t n, int32_t C, int64_t hw,
+                                        const float *mean, const float *invstd, double *sums, double *ws, double count,
+                                        float *dw, float *db, const float *relu_w, const float *relu_b, void *stream) {
+    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) && (relu_y != nullptr) + (relu_w != nullptr) +
+                                                                        (relu_bits != nullptr) <= 1,
+                  "bn_bwd_reduce: pass at most one of relu_y, relu_bits, (relu_w, relu_b)");
     BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
     return launch_colreduce<1>(x, dy, relu_y, n, C, hw, mean, invstd, sums, ws, count, fin, (hipStream_t)stream,
-                               relu_w, relu_b);
+                               relu_w, relu_b, relu_bits);
 }
 
 __global__ void k_bn_finalize(const double *__restrict__ sums, double count, int C, float eps, float momentum,
@@ -375,17 +388,34 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, i
 __global__ __launch_bounds__(256) void k_bn_apply4(const float4 *__restrict__ x, int64_t total4, int C4,
                                                    const float4 *__restrict__ mean, const float4 *__restrict__ invstd,
                                                    const float4 *__restrict__ w, const float4 *__restrict__ b,
-                                                   const float4 *__restrict__ res, int relu, float4 *__restrict__ y) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        int c4 = (int)(i % C4);
-        float4 v = x[i], m = mean[c4], s = invstd[c4], ww = w[c4], bb = b[c4];
-        v.x = (v.x - m.x) * s.x * ww.x + bb.x;
-        v.y = (v.y - m.y) * s.y * ww.y + bb.y;
-        v.z = (v.z - m.z) * s.z * ww.z + bb.z;
-        v.w = (v.w - m.w) * s.w * ww.w + bb.w;
-        if (res) { float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        y[i] = v;
+                                                   const float4 *__restrict__ res, int relu, float4 *__restrict__ y,
+                                                   uint32_t *__restrict__ bits) {
+    // the loop is uniform per workgroup (the tail iteration masks lanes instead of leaving): the ReLU bit mask is
+    // assembled from 8 neighbouring lanes with shuffles
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total4; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool ok = i < total4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            int c4 = (int)(i % C4);
+            v = x[i];
+            const float4 m = mean[c4], s = invstd[c4], ww = w[c4], bb = b[c4];
+            v.x = (v.x - m.x) * s.x * ww.x + bb.x;
+            v.y = (v.y - m.y) * s.y * ww.y + bb.y;
+            v.z = (v.z - m.z) * s.z * ww.z + bb.z;
+            v.w = (v.w - m.w) * s.w * ww.w + bb.w;
+            if (res) { float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            y[i] = v;
+        }
+        if (bits) {   // 4 bits per float4 (element > 0), 8 float4 per 32-bit word: bit 4 * (i % 8) + component
+            uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            uint32_t wv = nib << (4 * (threadIdx.x & 7));
+            wv |= __shfl_xor(wv, 1);
+            wv |= __shfl_xor(wv, 2);
+            wv |= __shfl_xor(wv, 4);
+            if (ok && (threadIdx.x & 7) == 0) bits[i >> 3] = wv;
+        }
     }
 }
 
@@ -441,16 +471,25 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_plane(const float *__restr
     }
 }
 
+extern "C" int64_t lidog_relu_bits_words(int64_t n, int32_t C) { return (n * (C / 4) + 7) / 8; }
+
 extern "C" int lidog_bn_apply(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean,
                               const float *invstd, const float *w, const float *b, const float *residual,
                               int32_t relu, float *y, void *stream) {
+    return lidog_bn_apply_bits(x, n, C, hw, mean, invstd, w, b, residual, relu, y, nullptr, stream);
+}
+
+extern "C" int lidog_bn_apply_bits(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean,
+                                   const float *invstd, const float *w, const float *b, const float *residual,
+                                   int32_t relu, float *y, uint32_t *relu_bits, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     int64_t total = n * C * hw;
+    LIDOG_REQUIRE(relu_bits == nullptr || (hw == 1 && C % 4 == 0), "bn_apply: bit masks only for [rows, C], C %% 4 == 0");
     if (total == 0) return 0;
     if (hw == 1 && C % 4 == 0) {
         k_bn_apply4<<<ew_grid(total / 4), 256, 0, st>>>((const float4 *)x, total / 4, C / 4, (const float4 *)mean,
                                                         (const float4 *)invstd, (const float4 *)w, (const float4 *)b,
-                                                        (const float4 *)residual, relu, (float4 *)y);
+                                                        (const float4 *)residual, relu, (float4 *)y, relu_bits);
     } else if (hw >= 1024) {
         int chunks = (int)cdiv64(hw, 8192);
         if (chunks > 64) chunks = 64;
@@ -490,7 +529,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float4 *__restrict_
                                                        const float *__restrict__ invstd, const float *__restrict__ w,
                                                        const double *__restrict__ sums, double inv_count,
                                                        float4 *__restrict__ dx, float4 *__restrict__ dres,
-                                                       const float *__restrict__ rb) {
+                                                       const float *__restrict__ rb,
+                                                       const uint32_t *__restrict__ rbits) {
     const int C = C4 * 4;
     const int64_t stride = (int64_t)gridDim.x * 256;  // launcher makes this a multiple of C4
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -511,8 +551,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply4(const float4 *__restrict_
     }
     for (; i < total4; i += stride) {
         float4 g = dy[i], xv = x[i];
-        if (ry) {
-            float4 y = ry[i];
+        if (ry || rbits) {
+            const float4 y = rbits ? lidog_relu_bits_as_float4(rbits, i) : ry[i];
             g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
             g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
         } else if (rb) {   // ReLU mask from the forward pass's pre-activation, recomputed bit for bit from x
@@ -542,10 +582,21 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
                                   int64_t hw, const float *mean, const float *invstd, const float *w,
                                   const double *sums, double count, float *dx, float *dres, float *dw, float *db,
                                   const float *relu_b, void *stream) {
+    return lidog_bn_bwd_apply_bits(dy, x, relu_y, nullptr, n, C, hw, mean, invstd, w, sums, count, dx, dres, dw, db,
+                                   relu_b, stream);
+}
+
+extern "C" int lidog_bn_bwd_apply_bits(const float *dy, const float *x, const float *relu_y,
+                                       const uint32_t *relu_bits, int64_t n, int32_t C, int64_t hw, const float *mean,
+                                       const float *invstd, const float *w, const double *sums, double count,
+                                       float *dx, float *dres, float *dw, float *db, const float *relu_b,
+                                       void *stream) {
     hipStream_t st = (hipStream_t)stream;
     int64_t total = n * C * hw;
     LIDOG_REQUIRE(relu_b == nullptr || (relu_y == nullptr && hw == 1 && C % 4 == 0),
                   "bn_bwd_apply: the ReLU mask can be recomputed from x only for [rows, C] with C %% 4 == 0");
+    LIDOG_REQUIRE(relu_bits == nullptr || (relu_y == nullptr && relu_b == nullptr && hw == 1 && C % 4 == 0),
+                  "bn_bwd_apply: a ReLU bit mask replaces relu_y / relu_b, [rows, C] with C %% 4 == 0 only");
     if (total > 0 && hw == 1 && C % 4 == 0) {
         int C4 = C / 4;
         int64_t total4 = total / 4;
@@ -559,7 +610,7 @@ extern "C" int lidog_bn_bwd_apply(const float *dy, const float *x, const float *
         k_bn_bwd_apply4<<<(unsigned)blocks, 256, 0, st>>>((const float4 *)dy, (const float4 *)x,
                                                           (const float4 *)relu_y, total4, C4, mean, invstd, w, sums,
                                                           count > 0 ? 1.0 / count : -1.0, (float4 *)dx,
-                                                          (float4 *)dres, relu_b);
+                                                          (float4 *)dres, relu_b, relu_bits);
     } else if (total > 0 && hw >= 1024) {
         int chunks = (int)cdiv64(hw, 8192);
         if (chunks > 64) chunks = 64;

@@ -68,3 +68,10 @@ __device__ __forceinline__ int lidog_find(const uint64_t *__restrict__ keys, con
         slot = (slot + 1) & mask;
     }
 }
+
+// ReLU bit mask of a [rows, C] matrix (C % 4 == 0) written by lidog_bn_apply_bits: bit 4 * (q % 8) + j of word q / 8 is
+// (element j of float4 number q) > 0.  Read back as a float4 of 1 / 0 so that the consumers keep their `y > 0` tests.
+__device__ __forceinline__ float4 lidog_relu_bits_as_float4(const uint32_t *__restrict__ bits, int64_t q) {
+    const uint32_t nib = bits[q >> 3] >> (4 * (int)(q & 7));
+    return make_float4((float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u));
+}

@@ -593,14 +593,15 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
     const float4 *__restrict__ T, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_list, int64_t n,
     int C4, const float4 *__restrict__ addend, float4 *__restrict__ out, const float4 *__restrict__ pre,
     const float4 *__restrict__ relu_y, const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ rw, const float *__restrict__ rb, double *__restrict__ partial) {
+    const float *__restrict__ rw, const float *__restrict__ rb, double *__restrict__ partial,
+    const uint32_t *__restrict__ rbits) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
     const int tid = threadIdx.x;
     const int r = tid / C4, c4 = tid % C4;
     const bool active = r < RB;
     const bool from_x = relu_y == nullptr && rw != nullptr;
-    const bool has_relu = relu_y != nullptr || from_x;
+    const bool has_relu = relu_y != nullptr || from_x || rbits != nullptr;
     double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         float m[4], is[4], gw[4] = {0, 0, 0, 0}, gb[4] = {1, 1, 1, 1};
@@ -636,7 +637,8 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
             if (o + step < n) {
                 const int64_t i1 = (o + step) * C4 + c4;
                 const float4 x0 = pre[i0], x1 = pre[i1];
-                const float4 y0 = relu_y ? relu_y[i0] : one, y1 = relu_y ? relu_y[i1] : one;
+                const float4 y0 = rbits ? lidog_relu_bits_as_float4(rbits, i0) : relu_y ? relu_y[i0] : one;
+                const float4 y1 = rbits ? lidog_relu_bits_as_float4(rbits, i1) : relu_y ? relu_y[i1] : one;
                 const float4 ad0 = addend ? addend[i0] : zero, ad1 = addend ? addend[i1] : zero;
                 float4 g0, g1;
                 reduce_row_list2(T, row_ptr, row_list, C4, o, o + step, c4, g0, g1);
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
                 emit(i1, g1, x1, y1, ad1);
             } else {
                 const float4 x0 = pre[i0];
-                const float4 y0 = relu_y ? relu_y[i0] : one;
+                const float4 y0 = rbits ? lidog_relu_bits_as_float4(rbits, i0) : relu_y ? relu_y[i0] : one;
                 const float4 ad0 = addend ? addend[i0] : zero;
                 emit(i0, reduce_row_list(T, row_ptr, row_list, C4, o, c4), x0, y0, ad0);
             }
@@ -669,21 +671,22 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
 
 extern "C" int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *row_ptr, const int32_t *row_list,
                                                 int64_t n, int32_t C, const float *addend, float *out,
-                                                const float *pre, const float *relu_y, const float *mean,
-                                                const float *invstd, const float *relu_w, const float *relu_b,
-                                                double *sums, double *partial_ws, double count, float *dw, float *db,
-                                                void *stream) {
+                                                const float *pre, const float *relu_y, const uint32_t *relu_bits,
+                                                const float *mean, const float *invstd, const float *relu_w,
+                                                const float *relu_b, double *sums, double *partial_ws, double count,
+                                                float *dw, float *db, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconv_reduce_rows_bwdstats: C must be a multiple of 4, <= 1024");
     LIDOG_REQUIRE(pre && mean && invstd && sums && partial_ws, "sconv_reduce_rows_bwdstats: null argument");
-    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) && !(relu_y && relu_w),
-                  "sconv_reduce_rows_bwdstats: pass either relu_y or (relu_w, relu_b)");
+    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) &&
+                      (relu_y != nullptr) + (relu_w != nullptr) + (relu_bits != nullptr) <= 1,
+                  "sconv_reduce_rows_bwdstats: pass at most one of relu_y, relu_bits, (relu_w, relu_b)");
     if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     const int C4 = C / 4;
     const int64_t nb = lidog_bn_bwd_reduce_blocks(n, C);   // the grid of lidog_bn_bwd_reduce: same partials
     k_sconv_reduce_rows4_bwdstats<<<(unsigned)nb, 256, 0, st>>>(
         (const float4 *)T, row_ptr, row_list, n, C4, (const float4 *)addend, (float4 *)out, (const float4 *)pre,
-        (const float4 *)relu_y, mean, invstd, relu_w, relu_b, partial_ws);
+        (const float4 *)relu_y, mean, invstd, relu_w, relu_b, partial_ws, relu_bits);
     BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
     lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
     LIDOG_LAUNCH_CHECK();

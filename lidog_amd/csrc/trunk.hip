@@ -25,7 +25,7 @@ enum { TM_K, TM_NIN, TM_NOUT, TM_P, TM_PAIR_IN, TM_PAIR_OUT, TM_RP_OUT, TM_RL_OU
        TM_NTILES, TM_NBR, TM_IDENT, TM_COLS = 16 };
 enum { TO_TYPE, TO_CONV, TO_IN, TO_OUT, TO_RELU, TO_RES, TO_FOLD, TO_B, TO_COLS = 8 };
 enum { TB_LEVEL, TB_CH, TB_EXT, TB_COLS = 4 };
-enum { REC_PRE, REC_MEAN, REC_INVSTD, REC_COLS = 4 };
+enum { REC_PRE, REC_MEAN, REC_INVSTD, REC_BITS, REC_COLS = 4 };   // REC_BITS: arena offset + 1 of the ReLU bit mask, 0 = none
 
 enum { KIND_K3 = 0, KIND_DOWN = 1, KIND_UP = 2, KIND_1X1 = 3, KIND_STEM = 4 };
 enum { OP_CONVBN = 0, OP_CAT = 1, OP_CONV = 2 };
@@ -207,7 +207,8 @@ inline const int32_t *tile_row(const int64_t *m, int r) { return P<const int32_t
 
 // Fusions the executor applies on top of the operator path's launch sequence (results stay bit-identical):
 //   1 = BatchNorm-backward statistics in the epilogue of the data-gradient reduction that produces the gradient
-int g_fusions = 1;
+//   2 = ReLU masks of the BatchNorm + residual + ReLU layers kept as bits (backward reads 1/32 of the saved output)
+int g_fusions = 3;
 
 // Optional timing of the gathered GEMM's launches (bench.py's roofline figure): HIP events on the launch stream around
 // every lidog_sconv_gemm call of the executor, with the launch's algorithmic FLOPs and bytes (every distinct input row
@@ -306,6 +307,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
     struct Pending {
         const int64_t *op, *c;
         float *pre, *mean, *invstd, *y;
+        uint32_t *bits;
         double *sums;
         int64_t n;
         int Cout;
@@ -333,6 +335,13 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             mean = (float *)ar.take(Cout * 4);
             r[REC_INVSTD] = ar.off;
             invstd = (float *)ar.take(Cout * 4);
+        }
+        // ReLU after a residual add: the mask cannot be recomputed from the BatchNorm input alone; kept as bits
+        uint32_t *bits = nullptr;
+        r[REC_BITS] = 0;
+        if (bn && (g_fusions & 2) && op[TO_RELU] && op[TO_RES] >= 0) {
+            r[REC_BITS] = ar.off + 1;
+            bits = (uint32_t *)ar.take(lidog_relu_bits_words(n, Cout) * 4);
         }
         float *rm = P<float>(c[TC_BNRM]), *rv = P<float>(c[TC_BNRV]);
         double *sums = nullptr;
@@ -372,7 +381,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
             TRYX(4, lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
         }
-        pd = Pending{op, c, pre, mean, invstd, y, sums, n, Cout, eps, mom};
+        pd = Pending{op, c, pre, mean, invstd, y, bits, sums, n, Cout, eps, mom};
         return 0;
     };
     auto bn_part = [&](const Pending &pd) -> int {
@@ -381,8 +390,8 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             TRY(lidog_bn_finalize(pd.sums, -1.0, pd.Cout, pd.eps, pd.mom, pd.mean, pd.invstd, P<float>(c[TC_BNRM]),
                                   P<float>(c[TC_BNRV]), stream));
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
-        TRYX(4, lidog_bn_apply(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
-                               P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, stream));
+        TRYX(4, lidog_bn_apply_bits(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
+                                    P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, stream));
         return 0;
     };
     for (int o = 0; o < n_ops; ++o) {
@@ -562,23 +571,25 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             const float *invstd = ctx.dry ? nullptr : (const float *)((char *)arena + r[REC_INVSTD]);
             const bool relu = op[TO_RELU] != 0, has_res = op[TO_RES] >= 0;
             const bool mask_from_x = relu && !has_res;  // Cout % 4 == 0 checked above
-            const float *ymask = (relu && !mask_from_x) ? bp[out_b] : nullptr;
+            const uint32_t *mbits = (!ctx.dry && r[REC_BITS]) ? (const uint32_t *)((char *)arena + r[REC_BITS] - 1) : nullptr;
+            const float *ymask = (relu && !mask_from_x && !r[REC_BITS]) ? bp[out_b] : nullptr;
             const float *bnw = P<const float>(c[TC_BNW]), *bnb = P<const float>(c[TC_BNB]);
             double *sums = bwd_sums[o];
             if (!sums) {
                 sums = (double *)sc.take((2 * Cout + 1) * 8);
                 int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
                 double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-                TRYX(8, lidog_bn_bwd_reduce(gout, pre, ymask, n, Cout, 1, mean, invstd, sums, ws, (double)n,
-                                            P<float>(c[TC_GBNW]), P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr,
-                                            mask_from_x ? bnb : nullptr, stream));
+                TRYX(8, lidog_bn_bwd_reduce_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, sums, ws, (double)n,
+                                                 P<float>(c[TC_GBNW]), P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr,
+                                                 mask_from_x ? bnb : nullptr, stream));
             }
             float *dx = (float *)ga.take(n * Cout * 4);
             float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
             // SyncBatchNorm: (sum dy', sum dy' xhat, rows) summed over the ranks; the apply kernel reads the global count
             if (sync) TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
-            TRYX(16, lidog_bn_bwd_apply(gout, pre, ymask, n, Cout, 1, mean, invstd, bnw, sums, sync ? -1.0 : (double)n, dx,
-                                   dres, nullptr, nullptr, mask_from_x ? bnb : nullptr, stream));
+            TRYX(16, lidog_bn_bwd_apply_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, bnw, sums,
+                                             sync ? -1.0 : (double)n, dx, dres, nullptr, nullptr,
+                                             mask_from_x ? bnb : nullptr, stream));
             if (has_res)
                 if (int rc = commit((int)op[TO_RES], dres)) return rc;
             gout = dx;
@@ -663,11 +674,13 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                     const float *p_mean = ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_MEAN]);
                     const float *p_invstd = ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_INVSTD]);
                     const bool p_relu = pop[TO_RELU] != 0, p_from_x = p_relu && pop[TO_RES] < 0;
-                    const float *p_y = (p_relu && !p_from_x) ? bp[in_b] : nullptr;
+                    const uint32_t *p_bits =
+                        (!ctx.dry && pr[REC_BITS]) ? (const uint32_t *)((char *)arena + pr[REC_BITS] - 1) : nullptr;
+                    const float *p_y = (p_relu && !p_from_x && !pr[REC_BITS]) ? bp[in_b] : nullptr;
                     double *sums = (double *)ga.take((2 * Cin + 1) * 8);   // lives until the producer's turn
                     double *ws = (double *)sc.take(lidog_bn_reduce_ws(Cin, 1) * 8);
                     TRYX(64, lidog_sconv_reduce_rows_bwdstats(T, rp, rl, n_in, Cin, folds ? gp[in_b] : nullptr, gx, p_pre,
-                                                              p_y, p_mean, p_invstd,
+                                                              p_y, p_bits, p_mean, p_invstd,
                                                               p_from_x ? P<const float>(pc[TC_BNW]) : nullptr,
                                                               p_from_x ? P<const float>(pc[TC_BNB]) : nullptr, sums, ws,
                                                               (double)n_in, P<float>(pc[TC_GBNW]), P<float>(pc[TC_GBNB]),

@@ -325,7 +325,8 @@ def test_output_stationary_conv_equals_two_pass_and_oracle(Cin, Cout, n):
     assert torch.equal(gx.cpu(), xo.grad)
 
 
-@pytest.mark.parametrize("C,mask", [(96, "from_x"), (96, "from_y"), (32, "none"), (256, "from_y")])
+@pytest.mark.parametrize("C,mask", [(96, "from_x"), (96, "from_y"), (32, "none"), (256, "from_y"), (96, "bits"),
+                                    (36, "bits")])
 def test_reduction_with_batchnorm_backward_statistics_in_its_epilogue(C, mask):
     """lidog_sconv_reduce_rows_bwdstats == lidog_sconv_reduce_rows followed by lidog_bn_bwd_reduce on its output: the
     gradient rows, the fp64 sums, the row count behind them and the parameter gradients, bit for bit"""
@@ -348,21 +349,49 @@ def test_reduction_with_batchnorm_backward_statistics_in_its_epilogue(C, mask):
     L = load()
     ws = torch.empty(L.lidog_bn_reduce_ws(C, 1), dtype=torch.float64, device="cuda")
     ry, rw, rb = (y, None, None) if mask == "from_y" else (None, w, b) if mask == "from_x" else (None, None, None)
+    bits = None
+    if mask == "bits":
+        # the mask as the forward pass leaves it (lidog_bn_apply_bits with a residual): same y, 1/32 of the bytes
+        res = torch.randn(n, C, device="cuda", generator=g)
+        bits = torch.full((L.lidog_relu_bits_words(n, C),), -1, dtype=torch.int32, device="cuda")
+        y2 = torch.empty(n, C, device="cuda")
+        call("lidog_bn_apply_bits", ptr(pre), n, C, 1, ptr(mean), ptr(invstd), ptr(w), ptr(b), ptr(res), 1, ptr(y2), ptr(bits))
+        y3 = torch.empty(n, C, device="cuda")
+        call("lidog_bn_apply", ptr(pre), n, C, 1, ptr(mean), ptr(invstd), ptr(w), ptr(b), ptr(res), 1, ptr(y3))
+        assert torch.equal(y2, y3)
+        y = y2
+        # every bit is the comparison y > 0 of its element
+        q = torch.arange(n * C // 4, device="cuda")
+        nib = (bits.long()[q >> 3] >> (4 * (q & 7))) & 15
+        want = ((y.view(-1, 4) > 0).long() * torch.tensor([1, 2, 4, 8], device="cuda")).sum(1)
+        assert torch.equal(nib, want)
     for add in (addend, None):
         out_a, out_b = torch.empty(n, C, device="cuda"), torch.empty(n, C, device="cuda")
         sums_a = torch.full((2 * C + 1,), -1.0, dtype=torch.float64, device="cuda")
         sums_b = sums_a.clone()
         dw_a, db_a, dw_b, db_b = (torch.empty(C, device="cuda") for _ in range(4))
         call("lidog_sconv_reduce_rows", ptr(T), ptr(rp), ptr(rl), n, C, None, ptr(add), ptr(out_a))
-        call("lidog_bn_bwd_reduce", ptr(out_a), ptr(pre), ptr(ry), n, C, 1, ptr(mean), ptr(invstd), ptr(sums_a), ptr(ws),
-             float(n), ptr(dw_a), ptr(db_a), ptr(rw), ptr(rb))
+        # reference: the two-pass path reading the saved output y (bits mode: y is what the bits were made from)
+        call("lidog_bn_bwd_reduce", ptr(out_a), ptr(pre), ptr(y if mask == "bits" else ry), n, C, 1, ptr(mean), ptr(invstd),
+             ptr(sums_a), ptr(ws), float(n), ptr(dw_a), ptr(db_a), ptr(rw), ptr(rb))
         call("lidog_sconv_reduce_rows_bwdstats", ptr(T), ptr(rp), ptr(rl), n, C, ptr(add), ptr(out_b), ptr(pre), ptr(ry),
-             ptr(mean), ptr(invstd), ptr(rw), ptr(rb), ptr(sums_b), ptr(ws), float(n), ptr(dw_b), ptr(db_b))
+             ptr(bits), ptr(mean), ptr(invstd), ptr(rw), ptr(rb), ptr(sums_b), ptr(ws), float(n), ptr(dw_b), ptr(db_b))
         assert torch.equal(out_a, out_b)
         assert torch.equal(sums_a, sums_b) and float(sums_b[2 * C]) == n
         assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+        if mask == "bits":   # the two-pass kernels with the bit mask: same sums, same dx / dres as with y
+            sums_c = torch.empty_like(sums_a)
+            call("lidog_bn_bwd_reduce_bits", ptr(out_a), ptr(pre), None, ptr(bits), n, C, 1, ptr(mean), ptr(invstd),
+                 ptr(sums_c), ptr(ws), float(n), ptr(dw_b), ptr(db_b), None, None)
+            assert torch.equal(sums_c, sums_a)
+            dx_a, dx_b, dr_a, dr_b = (torch.empty(n, C, device="cuda") for _ in range(4))
+            call("lidog_bn_bwd_apply", ptr(out_a), ptr(pre), ptr(y), n, C, 1, ptr(mean), ptr(invstd), ptr(w), ptr(sums_a),
+                 float(n), ptr(dx_a), ptr(dr_a), None, None, None)
+            call("lidog_bn_bwd_apply_bits", ptr(out_a), ptr(pre), None, ptr(bits), n, C, 1, ptr(mean), ptr(invstd), ptr(w),
+                 ptr(sums_a), float(n), ptr(dx_b), ptr(dr_b), None, None, None)
+            assert torch.equal(dx_a, dx_b) and torch.equal(dr_a, dr_b)
         # and the sums are what they should be (float64 reference)
-        gm = out_a.double() * ((y > 0) if mask == "from_y" else ((pre - mean) * invstd * w + b > 0) if mask == "from_x"
+        gm = out_a.double() * ((y > 0) if mask in ("from_y", "bits") else ((pre - mean) * invstd * w + b > 0) if mask == "from_x"
                                else torch.ones_like(y, dtype=torch.bool))
         xh = ((pre - mean) * invstd).double()
         ref = torch.cat([gm.sum(0), (gm * xh).sum(0)])

@@ -45,11 +45,12 @@ def _assert_same(a, b, what):
             assert torch.equal(a[k], b[k]), f"{what} {k}: max |diff| {(a[k] - b[k]).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("fusions", [1, 0], ids=["fused", "plain_sequence"])
+@pytest.mark.parametrize("fusions", [3, 1, 0], ids=["fused", "bwdstats_only", "plain_sequence"])
 @pytest.mark.parametrize("overlap", [True, False])
 def test_executor_step_is_bit_identical_to_the_operator_path(overlap, fusions):
     """3 optimiser steps of the LiDOG step (Adam on flat buffers), executor on vs off; with the executor's fusions
-    (BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction) and without them"""
+    (BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction, ReLU masks of the residual
+    layers as bits) and without them"""
     from lidog_amd import me as ME, trunk
     from lidog_amd.trainer import LiDOGStep
     from lidog_amd.optim import make_optimizer
