@@ -95,7 +95,7 @@ int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t n_in, int3
                            void *stream);
 /* Per-row lists of a rule book: row_ptr [n+1], row_list [P] = the pair positions of row o (entries of pos [K][n] that
  * are >= 0) in ascending offset order; what lidog_sconv_reduce_rows[_stats] walk.  mark_k >= 0: the entry of that
- * offset is stored as -1 (lidog_sconv_center_reduce computes the centre offset itself).  ws: ceil((n+1)/1024)+1 ints. */
+ * offset is stored as -1 (a consumer that computes that offset's product itself; unused by this library's path).  ws: ceil((n+1)/1024)+1 ints. */
 int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t mark_k, int32_t *row_ptr,
                           int32_t *row_list, int32_t *ws, void *stream);
 
@@ -151,18 +151,6 @@ int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *row_ptr, con
 int lidog_sconv_reduce_rows_bn(const float *T, const int32_t *row_ptr, const int32_t *row_list, int64_t n, int32_t C,
                                const float *bias, const float *mean, const float *invstd, const float *w,
                                const float *b, const float *residual, int32_t relu, float *out, void *stream);
-/* Reduction with the centre offset of a stride-1 odd kernel fused in (csrc/sconv_center.hip): out [n, Cout] = sum over
- * the per-row lists in ascending offset order, where the entry marked -1 is A[o] . Wc (Wc [Cin, Cout] = the centre
- * offset's weights), computed here on the matrix cores, and every other entry is a row of T (written by
- * lidog_sconv_gemm over the rule book WITHOUT its centre segment) -- the additions of the two-pass path in the same
- * order, bit-identical; + bias + addend.  sums != NULL: BatchNorm statistics as lidog_sconv_reduce_stats leaves them
- * (partial_ws: lidog_sconv_center_reduce_ws(n, Cout) doubles).  Cin, Cout multiples of 32; lists of a 3^3 kernel. */
-int64_t lidog_sconv_center_reduce_ws(int64_t n, int32_t C);
-int lidog_sconv_center_reduce(const float *A, const float *Wc, const float *T, const int32_t *row_ptr,
-                              const int32_t *row_list, int64_t n, int32_t Cin, int32_t Cout, const float *bias,
-                              const float *addend, float *out, double *sums, double *partial_ws, double count,
-                              float eps, float momentum, float *mean, float *invstd, float *running_mean,
-                              float *running_var, void *stream);
 /* count / eps / momentum / mean / invstd / running_*: as for lidog_bn_stats below (the last kernel of the
  * reduction also stores the row count behind the sums and, when mean != NULL, finalises the statistics). */
 
@@ -171,19 +159,6 @@ int lidog_sconv_center_reduce(const float *A, const float *Wc, const float *T, c
  * Cout in {16, 32, 64}. */
 int lidog_sconv_cin1(const float *x, const int32_t *nbr, const float *W, const float *bias, int64_t n, int32_t K,
                      int32_t C, float *out, void *stream);
-
-/* Output-stationary convolution for stride-1 odd kernels (csrc/sconv_os.hip): out = sum_k A[pair_in] . W[k] without
- * the product rows T and the reduction pass; bit-identical to lidog_sconv_gemm + lidog_sconv_reduce.
- * seg [K][ceil(n_out/256)+1] int32 from lidog_sconv_os_segments (first pair of every (offset, 256-row block)).
- * reverse = 1 with A = gout and W = transposed weights gives the data gradient (the map is symmetric).
- * partial (may be NULL): ceil(n_out/256) x 2*Cout doubles, BatchNorm partial sums of out (then lidog_bn_sums_finish).
- * Cin in {32,64,96,128}, Cout % 32 == 0. */
-int32_t lidog_sconv_os_block_rows(void);
-int lidog_sconv_os_segments(const int32_t *pair_out, const int64_t *k_off, int32_t K, int64_t n_out, int32_t *seg,
-                            void *stream);
-int lidog_sconv_os(const float *A, const int32_t *pair_in, const int32_t *pair_out, const int32_t *seg, int32_t K,
-                   int64_t n_out, const float *W, int32_t reverse, int32_t Cin, int32_t Cout, float *out,
-                   double *partial, void *stream);
 
 /* gW[k] = sum over the pairs p of offset k of A[pair_a[p]]^T . G[pair_g[p]]   ([Cin,Cout] per k).
  * The pair list is cut on the host into work items of (nearly) equal length that never straddle an offset:

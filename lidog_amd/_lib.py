@@ -30,8 +30,6 @@ SIGNATURES = {
     "lidog_sconv_reduce_stats_ws": [_i64, _i32],
     "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_kernel_map_rows": [_p, _i64, _i32, _i32, _p, _p, _p, _p],
-    "lidog_sconv_center_reduce_ws": [_i64, _i32],
-    "lidog_sconv_center_reduce": [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_rows_bn": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_sconv_reduce_rows_stats": [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
@@ -39,9 +37,6 @@ SIGNATURES = {
     "lidog_bn_bwd_reduce_blocks": [_i64, _i32],
     "lidog_stats_max_blocks": [],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
-    "lidog_sconv_os_block_rows": [],
-    "lidog_sconv_os_segments": [_p, _p, _i32, _i64, _p, _p],
-    "lidog_sconv_os": [_p, _p, _p, _p, _i32, _i64, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
     "lidog_set_sparse_core": [_i32],
@@ -102,7 +97,7 @@ SIGNATURES = {
                              _i64, _p, _p, _i32, _i32, _p, _p, _p],
 }
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
-             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_sconv_center_reduce_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
+             "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
              "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64, "lidog_bitmap_words": _i64,
              "lidog_bn_bwd_reduce_blocks": _i64, "lidog_relu_bits_words": _i64}
 

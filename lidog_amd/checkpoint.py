@@ -30,12 +30,16 @@ def _cpu(v):
 
 def save_lightning_checkpoint(model, path, epoch=0, global_step=0, optimizer=None, scheduler=None):
     """writes the keys eval_target.py / --auto_resume of the reference read back (`epoch`, `global_step`,
-    `state_dict` with the `model.` prefix) plus Lightning's `optimizer_states` / `lr_schedulers` lists, which
-    load_training_checkpoint uses to resume (trainer.fit(ckpt_path=...), train_lidog.py:298-301)"""
+    `state_dict` with the `model.` prefix) plus Lightning's `optimizer_states` / `lr_schedulers` lists
+    (trainer.fit(ckpt_path=...), train_lidog.py:298-301).  `optimizer_states[0]` is in torch.optim's own layout
+    (`state` + `param_groups`, lidog_amd.optim._FlatOptimizer.torch_state_dict), so torch.optim.Adam / SGD over the
+    reference model's parameters can load it and a checkpoint written by the reference loads here; the scheduler entry
+    carries `last_epoch` (the only field both sides need)."""
     ckpt = {"epoch": epoch, "global_step": global_step,
             "state_dict": {"model." + k: v.detach().cpu() for k, v in model.state_dict().items()}}
     if optimizer is not None:
-        ckpt["optimizer_states"] = [_cpu(optimizer.state_dict())]
+        to_torch = getattr(optimizer, "torch_state_dict", None)
+        ckpt["optimizer_states"] = [_cpu(to_torch() if to_torch is not None else optimizer.state_dict())]
     if scheduler is not None:
         ckpt["lr_schedulers"] = [scheduler.state_dict()]
     tmp = path + ".tmp"

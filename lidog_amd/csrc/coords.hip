@@ -646,8 +646,8 @@ __global__ __launch_bounds__(256) void k_rows_fill(const int32_t *__restrict__ p
     }
 }
 
-// ws: ceil((n + 1) / 1024) + 1 ints.  mark_k >= 0: the entry of that offset is stored as -1 (the centre offset whose
-// product lidog_sconv_center_reduce computes itself), -1: every entry is a pair position.
+// ws: ceil((n + 1) / 1024) + 1 ints.  mark_k >= 0: the entry of that offset is stored as -1 (for a consumer that
+// computes that offset's product itself; this library passes -1: every entry is a pair position).
 extern "C" int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t mark_k, int32_t *row_ptr,
                                      int32_t *row_list, int32_t *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -10,7 +10,7 @@
 //   t = one-hot (DICE) or label-smoothed one-hot (soft: 1-eps / eps/(C-1)); rows with the ignore label are skipped.
 #include "common.h"
 
-#define DL_MAXC 16
+#define DL_MAXC 20
 #define DL_MAX_BLOCKS 1024
 
 template <int C>
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_dice_sums(const float *__restrict__ log
 
 // one block: sums[4C] over the partials in block order; loss; coef[2C] = (a_c, b_c) with
 // d loss / d p_rc = a_c * t_rc + b_c * (2 p_rc or 1)
-__global__ __launch_bounds__(512) void k_dice_finish(const double *__restrict__ partial, int nb, int C, int use_tmask,
+__global__ __launch_bounds__(1024) void k_dice_finish(const double *__restrict__ partial, int nb, int C, int use_tmask,
                                                      float offset, float *__restrict__ loss, float *__restrict__ coef) {
     // 8 lanes per column: lane l adds the partials b = l, l + 8, ...; the 8 lane sums are combined in lane order
     // (fixed order: bit-reproducible).  One thread per column took 56 us on the step's forward -> backward seam.
@@ -150,13 +150,30 @@ static int dice_blocks(int64_t n) {
 
 extern "C" int64_t lidog_dice_ws(int32_t C) { return (int64_t)DL_MAX_BLOCKS * 4 * C; }
 
+// 7 classes in every configuration of the reference (configs/*: out_channels 7); the other counts (binary heads, 16-class
+// nuScenes, 19 / 20-class SemanticKITTI label sets) cost one instantiation each
 #define DICE_DISPATCH(CALL)                                                     \
     switch (C) {                                                                \
         case 2: CALL(2); break;                                                 \
+        case 3: CALL(3); break;                                                 \
+        case 4: CALL(4); break;                                                 \
+        case 5: CALL(5); break;                                                 \
+        case 6: CALL(6); break;                                                 \
         case 7: CALL(7); break;                                                 \
         case 8: CALL(8); break;                                                 \
+        case 9: CALL(9); break;                                                 \
+        case 10: CALL(10); break;                                               \
+        case 11: CALL(11); break;                                               \
+        case 12: CALL(12); break;                                               \
+        case 13: CALL(13); break;                                               \
+        case 14: CALL(14); break;                                               \
+        case 15: CALL(15); break;                                               \
         case 16: CALL(16); break;                                               \
-        default: LIDOG_REQUIRE(false, "dice: C must be 2, 7, 8 or 16");         \
+        case 17: CALL(17); break;                                               \
+        case 18: CALL(18); break;                                               \
+        case 19: CALL(19); break;                                               \
+        case 20: CALL(20); break;                                               \
+        default: LIDOG_REQUIRE(false, "dice: C must be in [2, 20]");            \
     }
 
 extern "C" int lidog_dice_fwd(const float *logits, const int64_t *target, int64_t n, int32_t C, int64_t ignore_label,
@@ -170,7 +187,7 @@ extern "C" int lidog_dice_fwd(const float *logits, const int64_t *target, int64_
     k_dice_sums<C_><<<nb, 256, 0, st>>>(logits, target, n, ignore_label, has_ignore, t_on, t_off, powerize, ws)
     DICE_DISPATCH(CALL)
 #undef CALL
-    k_dice_finish<<<1, 512, 0, st>>>(ws, nb, C, use_tmask, offset, loss, coef);
+    k_dice_finish<<<1, 1024, 0, st>>>(ws, nb, C, use_tmask, offset, loss, coef);   // 8 lanes x 4C <= 80 columns
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

@@ -40,8 +40,7 @@ def kernel_offsets(kernel_size, tensor_stride, dilation=1):
 
 def _tiles_host(k_off_host, skip_k=-1):
     """tile descriptors (tile_k, tile_row0, tile_rows) for 128-row tiles that never straddle an offset:
-    (int32 [3, n_tiles] numpy array, n_tiles).  `skip_k`: an offset left out (the centre offset when the reduction
-    pass computes it itself, csrc/sconv_center.hip).
+    (int32 [3, n_tiles] numpy array, n_tiles).  `skip_k`: an offset left out.
     Launch order: tiles at the same relative position of their offset segment run together.  Pairs are sorted by output
     row inside a segment, so these tiles gather (nearly) the same feature rows for different offsets while they are
     still in L2 instead of re-fetching them K times from HBM.  (Host code of the library, csrc/hostprep.hip: the numpy
@@ -82,13 +81,6 @@ class _Arena:
         return dev, out
 
 
-def _center_of(key):
-    """index of the centre offset of a kernel-map key (s_in, s_out, kernel size, dilation) whose centre segment is the
-    identity map (same coordinate map on both sides, odd kernel), else -1"""
-    s_in, s_out, ksize, _ = key
-    return (ksize ** 3) // 2 if (s_in == s_out and ksize % 2 == 1 and ksize > 1) else -1
-
-
 class _CoordMap:
     __slots__ = ("coords", "keys", "vals", "cap", "n", "bits", "box")
 
@@ -107,10 +99,6 @@ class KernelMap:
         self.pair_in, self.pair_out, self._pos_out, self._pos_in, self.nbr = pair_in, pair_out, pos_out, pos_in, nbr
         self.tiles, self.n_tiles = tiles if tiles is not None else _tiles(k_off_host, pair_in.device)
         self._rows = {}
-        # centre offset of a stride-1 odd kernel: its segment of the rule book is the identity map (every voxel pairs
-        # with itself), which lets the reduction pass compute its products itself (csrc/sconv_center.hip)
-        self.center = -1
-        self._tiles_nc = None
 
     def _pos_table(self, side):
         """[K, n] pair position of (offset, row) or -1.  Written with the rule book for K <= 27; a 5^3 map (the Cin = 1
@@ -131,31 +119,18 @@ class KernelMap:
     pos_out = property(lambda self: self._pos_table("out"))
     pos_in = property(lambda self: self._pos_table("in"))
 
-    def set_center(self, k, tiles_nc=None):
-        if int(self.k_off_host[k + 1]) - int(self.k_off_host[k]) == self.n_out == self.n_in:
-            self.center = k
-            self._tiles_nc = tiles_nc
-
-    @property
-    def tiles_nc(self):
-        """(tile descriptors, tile count, pairs) of the rule book without its centre segment"""
-        if self._tiles_nc is None:
-            self._tiles_nc = _tiles(self.k_off_host, self.pair_in.device, self.center)
-        return self._tiles_nc + (self.P - self.n_out,)
-
-    def rows(self, side, mark_center=False):
+    def rows(self, side):
         """(row_ptr int32 [n+1], row_list int32 [P]) of the output ("out") or input ("in") rows: the pair positions
         of every row in ascending offset order -- what the reduction pass walks (include/lidog_amd.h:
-        lidog_kernel_map_rows); `mark_center`: the centre offset's entry is -1.  Built with the map when it is
-        prepared ahead of time, else on first use."""
-        key = (side, mark_center)
+        lidog_kernel_map_rows).  Built with the map when it is prepared ahead of time, else on first use."""
+        key = side
         if key not in self._rows:
             pos, n = (self.pos_out, self.n_out) if side == "out" else (self.pos_in, self.n_in)
             dev = pos.device
             row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
             row_list = torch.empty(max(self.P, 1), dtype=torch.int32, device=dev)
             ws = torch.empty((n + 1 + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
-            call("lidog_kernel_map_rows", ptr(pos), n, self.K, self.center if mark_center else -1, ptr(row_ptr),
+            call("lidog_kernel_map_rows", ptr(pos), n, self.K, -1, ptr(row_ptr),
                  ptr(row_list), ptr(ws))
             self._rows[key] = (row_ptr, row_list)
         return self._rows[key]
@@ -359,17 +334,13 @@ class CoordinateManager:
             k_off_host = hosts[off:off + K + 1]
             off += K + 1
             desc, n_tiles = _tiles_host(k_off_host)
-            nc = None
-            if _center_of(key) >= 0 and _CENTER_FUSED:
-                desc_nc, n_nc = _tiles_host(k_off_host, _center_of(key))
-                nc = (arena.add(desc_nc), n_nc)
-            todo.append(("kmap", key, pd, k_off_host, arena.add(desc), n_tiles, nc))
+            todo.append(("kmap", key, pd, k_off_host, arena.add(desc), n_tiles))
         for key in want:
             if key[0] == "identity":
                 n = self.maps[key[1]].n
                 if n not in self.identity:
                     desc, n_tiles = _tiles_host([0, n])
-                    todo.append(("identity", n, None, [0, n], arena.add(desc), n_tiles, None))
+                    todo.append(("identity", n, None, [0, n], arena.add(desc), n_tiles))
         # weight-gradient work items of every (map, Cin, Cout) seen
         items_todo = []
         k_off_of = {t[1]: t[3] for t in todo}
@@ -391,10 +362,9 @@ class CoordinateManager:
                 items_todo.append((key, chunk, arena.add(items), total, arena.add(item_off)))
         dev, views = arena.ship(self.device)
         self._own(dev)
-        for kind, key, pd, k_off_host, slot, n_tiles, nc in todo:
+        for kind, key, pd, k_off_host, slot, n_tiles in todo:
             if kind == "kmap":
-                tiles_nc = (views[nc[0]], nc[1]) if nc is not None else None
-                self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, (views[slot], n_tiles), key, tiles_nc)
+                self.kmaps[key] = self._kernel_map_finish(pd, k_off_host, (views[slot], n_tiles), key)
             else:
                 self.identity[key] = _IdentityMap(key, self.device, (views[slot], n_tiles))
                 self._own(self.identity[key].k_off, self.identity[key].rows)
@@ -526,22 +496,14 @@ class CoordinateManager:
         self._own(*[t for t in (nbr, k_off, pair_in, pair_out, pos_out, pos_in) if t is not None])
         return (K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr)
 
-    def _kernel_map_finish(self, pd, k_off_host, tiles, key=None, tiles_nc=None):
+    def _kernel_map_finish(self, pd, k_off_host, tiles, key=None):
         K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr = pd
         P = int(k_off_host[-1])
         m = KernelMap(K, n_in, n_out, k_off, k_off_host, pair_in[:P], pair_out[:P], pos_out, pos_in, nbr, tiles)
-        if key is not None and _center_of(key) >= 0:
-            m.set_center(_center_of(key), tiles_nc)
-        # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient, the centre
-        # entry marked; 2^3 stride 2: the strided convolution's forward and the transposed convolution's data
-        # gradient, both over the coarse rows)
+        # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient; 2^3 stride 2:
+        # the strided convolution's forward and the transposed convolution's data gradient, both over the coarse rows)
         if K == 27:
-            mark = m.center >= 0 and _CENTER_FUSED     # the lists the reduction passes will ask for
-            self._own(*m.rows("out", False), *m.rows("in", False))
-            if mark:
-                self._own(*m.rows("out", True), *m.rows("in", True))
-                if m._tiles_nc is None:
-                    self._own(m.tiles_nc[0])
+            self._own(*m.rows("out"), *m.rows("in"))
         elif K == 8:
             self._own(*m.rows("out"))
         return m
@@ -703,33 +665,16 @@ def _grad_out(param, shape):
 
 
 def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles=None):
-    """`tiles`: (descriptors, count, pairs) of a subset of the rule book (KernelMap.tiles_nc), default all of it"""
+    """`tiles`: (descriptors, count, pairs) of a subset of the rule book, default all of it"""
     desc, n_tiles = (tiles[0], tiles[1]) if tiles is not None else (m.tiles, m.n_tiles)
     call("lidog_sconv_gemm", ptr(A), ptr(gather), ptr(B), ptr(bias), ptr(desc[0]), ptr(desc[1]), ptr(desc[2]),
          n_tiles, Cin, Cout, ptr(out), ptr(scatter))
 
 
-def _use_center(m, Cin, Cout):
-    """the reduction pass computes the centre offset itself (csrc/sconv_center.hip): 3^3 stride-1 maps, channel counts
-    the matrix-core kernels take, matrix cores selected"""
-    return getattr(m, "center", -1) >= 0 and m.K == 27 and Cin % 32 == 0 and Cout % 32 == 0 and \
-        _CENTER_FUSED and m.n_out >= _CENTER_MIN_ROWS and min(Cin, Cout) >= _CENTER_MIN_CH and \
-        _lib.load().lidog_get_sparse_core() == 1
-
-
-# Measured on MI355X (scripts/bench_pair.py): the saving is the centre segment's product rows (written + read: 23 % of
-# T at stride 1), the price is that the list walk runs in a register-heavy matrix-core kernel with a third of the
-# waves of the stand-alone reduction.  GEMM + reduction back to back: stride-1 layers with >= 96 channels 1.12-1.14 x,
-# stride 2 / 96 channels 1.02 x, narrower or deeper layers 0.78-0.99 x.  In the full training step (weight gradients
-# co-running on the second stream) the difference vanishes: 50.54 vs 50.57 ms per step, twice.  OFF by default;
-# LIDOG_CENTER_FUSED=1 turns it on for the layers above the two thresholds (results are bit-identical either way).
-_CENTER_FUSED = os.environ.get("LIDOG_CENTER_FUSED", "0") == "1"
 # occupancy bitmaps in front of the kernel maps' hash probes (CoordinateManager._bitmap); 0 = plain probes
 _BITMAPS = os.environ.get("LIDOG_MAP_BITMAPS", "1") != "0"
 _BITMAP_MAX_BYTES = int(os.environ.get("LIDOG_MAP_BITMAP_MAX_MB", "1024")) << 20
 _BITMAP_MIN_ROWS = int(os.environ.get("LIDOG_MAP_BITMAP_MIN_ROWS", "40000"))
-_CENTER_MIN_ROWS = int(os.environ.get("LIDOG_CENTER_MIN_ROWS", "250000"))
-_CENTER_MIN_CH = int(os.environ.get("LIDOG_CENTER_MIN_CH", "96"))
 
 
 # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X (LIDOG_WGRAD_BLOCKS: A/B runs)
@@ -824,30 +769,10 @@ class _SparseConvFn(torch.autograd.Function):
             call("lidog_sconv_cin1", ptr(x), ptr(m.nbr), ptr(W3), ptr(bias), n_out, K, Cout, ptr(out))
         else:
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
-            center = not swap and _use_center(m, Cin, Cout)
-            _gemm(x, g_in, W3, None, m, Cin, Cout, T, None, m.tiles_nc if center else None)
+            _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
             if Cout % 4 == 0:
-                row_ptr, row_list = m.rows("in" if swap else "out", center)
-            if center:
-                # reduction with the centre offset's products computed in place (no product rows for it)
-                dev = x.device
-                want = stats is not None and Cout <= 1024
-                sums = ws = None
-                fin = (float(n_out), 0.0, 0.0, None, None, None, None)
-                if want:
-                    sums = stats.sums_out if stats.sums_out is not None else \
-                        torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
-                    ws = torch.empty(_lib.load().lidog_sconv_center_reduce_ws(n_out, Cout), dtype=torch.float64,
-                                     device=dev)
-                    if not stats.sync:
-                        stats.mean = torch.empty(Cout, dtype=torch.float32, device=dev)
-                        stats.invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
-                        fin = (float(n_out), stats.eps, stats.momentum, ptr(stats.mean), ptr(stats.invstd),
-                               ptr(stats.running_mean), ptr(stats.running_var))
-                    stats.sums = sums
-                call("lidog_sconv_center_reduce", ptr(x), ptr(W3[m.center]), ptr(T), ptr(row_ptr), ptr(row_list), n_out,
-                     Cin, Cout, ptr(bias), None, ptr(out), ptr(sums), ptr(ws), *fin)
-            elif stats is not None and Cout % 4 == 0 and Cout <= 1024:
+                row_ptr, row_list = m.rows("in" if swap else "out")
+            if stats is not None and Cout % 4 == 0 and Cout <= 1024:
                 dev = x.device
                 sums = stats.sums_out if stats.sums_out is not None else \
                     torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
@@ -932,17 +857,11 @@ class _SparseConvFn(torch.autograd.Function):
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, gx, g_in)
             else:
                 T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
-                center = not swap and _use_center(m, Cout, Cin)
-                _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None, m.tiles_nc if center else None)
+                _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)
                 if ctx.needs_input_grad[1] and behind:
                     gW = queue_wgrad()
                 add = gskip if (gskip is not None and Cin % 4 == 0) else None
-                if center:
-                    row_ptr, row_list = m.rows("in", True)
-                    call("lidog_sconv_center_reduce", ptr(gout), ptr(Wt[m.center]), ptr(T), ptr(row_ptr), ptr(row_list),
-                         n_in, Cout, Cin, None, ptr(add), ptr(gx), None, None, float(n_in), 0.0, 0.0, None, None, None,
-                         None)
-                elif Cin % 4 == 0:
+                if Cin % 4 == 0:
                     row_ptr, row_list = m.rows("out" if swap else "in")
                     call("lidog_sconv_reduce_rows", ptr(T), ptr(row_ptr), ptr(row_list), n_in, Cin, None, ptr(add),
                          ptr(gx))

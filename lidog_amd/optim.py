@@ -297,7 +297,48 @@ class _FlatOptimizer:
         sd.update({k: getattr(self, k) for k in self._state})
         return sd
 
+    def torch_state_dict(self):
+        """the state in torch.optim's layout -- `state` {index: {step, per-parameter tensors}} + `param_groups` with the
+        parameters numbered in model.parameters() order -- i.e. what Lightning stores as `optimizer_states[0]` and what
+        the reference's `trainer.fit(ckpt_path=...)` (train_lidog.py:298-301) hands to torch.optim.Adam / SGD
+        .load_state_dict.  Parameters that never received a gradient have no entry, as in torch."""
+        state = {}
+        for i, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            if self.param_steps[i] == 0:
+                continue
+            entry = {k: getattr(self, k)[off:off + p.numel()].view(p.shape).detach().clone() for k in self._state}
+            if "exp_avg" in entry:
+                entry["step"] = torch.tensor(float(self.param_steps[i]))
+            state[i] = entry
+        group = dict(self._torch_group(), lr=self.lr, initial_lr=self.base_lr, params=list(range(len(self.flat.params))))
+        return {"state": state, "param_groups": [group]}
+
+    def _load_torch_layout(self, sd):
+        """inverse of torch_state_dict: a checkpoint written by the reference (torch.optim state through Lightning)"""
+        groups = sd["param_groups"]
+        order = [i for g in groups for i in g["params"]]
+        if len(order) != len(self.flat.params):
+            raise ValueError(f"optimizer state for {len(order)} parameters, the model has {len(self.flat.params)}")
+        for k in self._state:
+            getattr(self, k).zero_()
+        self.param_steps = [0] * len(self.flat.params)
+        for pos, idx in enumerate(order):
+            entry = sd["state"].get(idx)
+            if entry is None:
+                continue
+            p, off = self.flat.params[pos], self.flat.offsets[pos]
+            for k in self._state:
+                if entry.get(k) is not None:
+                    getattr(self, k)[off:off + p.numel()].copy_(entry[k].reshape(-1).to(getattr(self, k).device))
+            step = entry.get("step", 1)
+            self.param_steps[pos] = int(step.item() if torch.is_tensor(step) else step)
+        self.lr = float(groups[0]["lr"])
+        self.base_lr = float(groups[0].get("initial_lr", groups[0]["lr"]))
+        self.transposed.refresh()
+
     def load_state_dict(self, sd):
+        if "state" in sd and "param_groups" in sd:     # torch.optim layout (a checkpoint of the reference / Lightning)
+            return self._load_torch_layout(sd)
         for k in self._state:
             getattr(self, k).copy_(sd[k].to(getattr(self, k).device))
         self.lr, self.base_lr = float(sd["lr"]), float(sd.get("base_lr", sd["lr"]))
@@ -319,6 +360,10 @@ class FlatAdam(_FlatOptimizer):
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
+
+    def _torch_group(self):
+        return {"betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None}
 
     def step(self):
         scale = self._prepare()
@@ -342,6 +387,10 @@ class FlatSGD(_FlatOptimizer):
             raise ValueError("Nesterov momentum requires a momentum and zero dampening")   # torch's own check
         self.momentum, self.weight_decay, self.nesterov = momentum, weight_decay, nesterov
         self.momentum_buffer = torch.zeros_like(self.flat.flat)
+
+    def _torch_group(self):
+        return {"momentum": self.momentum, "dampening": 0, "weight_decay": self.weight_decay, "nesterov": self.nesterov,
+                "maximize": False, "foreach": None, "differentiable": False, "fused": None}
 
     def step(self):
         scale = self._prepare()
@@ -380,10 +429,13 @@ class _Scheduler:
         return self.optimizer.lr
 
     def state_dict(self):
-        return {"last_epoch": self.last_epoch, "base_lr": self.base_lr, "kind": type(self).__name__}
+        # last_epoch / base_lrs / _last_lr are the keys of torch's schedulers (what Lightning stores and restores)
+        return {"last_epoch": self.last_epoch, "base_lr": self.base_lr, "base_lrs": [self.base_lr],
+                "_last_lr": [self.optimizer.lr], "kind": type(self).__name__}
 
     def load_state_dict(self, sd):
-        self.last_epoch, self.base_lr = int(sd["last_epoch"]), float(sd["base_lr"])
+        self.last_epoch = int(sd["last_epoch"])
+        self.base_lr = float(sd["base_lr"] if "base_lr" in sd else sd["base_lrs"][0])
 
 
 class CosineAnnealingLR(_Scheduler):

@@ -23,6 +23,8 @@ from . import _lib, me as ME
 from ._lib import call, call_on
 
 ENABLED = os.environ.get("LIDOG_TRUNK_EXEC", "1") != "0"
+if "LIDOG_TRUNK_FUSIONS" in os.environ:     # A/B runs: bit mask of the executor's fusions (see set_fusions)
+    _lib.load().lidog_trunk_fusions(int(os.environ["LIDOG_TRUNK_FUSIONS"]))
 
 KIND_K3, KIND_DOWN, KIND_UP, KIND_1X1, KIND_STEM = range(5)
 OP_CONVBN, OP_CAT, OP_CONV = range(3)
@@ -241,8 +243,6 @@ def _eligible(model, prog, x):
         return False
     f = x.F
     if not (f.is_cuda and f.dtype == torch.float32 and not f.requires_grad and x.coordinate_map_key == 1):
-        return False
-    if ME._CENTER_FUSED:
         return False
     group = prog.bns[0]._sync_group() if prog.bns else None
     for bnm in prog.bns:
@@ -481,8 +481,15 @@ class _TrunkFn(torch.autograd.Function):
         return tuple(outs[1:])
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, *gouts):
         run = ctx.run
+        if run.done:
+            # the activation arena of this pass may already belong to a later forward pass (it is reused as soon as a
+            # backward pass has run): a second backward over the same graph (retain_graph=True, two losses
+            # backpropagated one after the other) would silently read overwritten activations
+            raise RuntimeError("lidog_amd.trunk: this forward pass has already been backpropagated once; call the model "
+                               "again (or set LIDOG_TRUNK_EXEC=0 to use the operator path, which keeps its tensors)")
         prog = run.prog
         outs = ctx.saved_tensors
         dev = outs[0].device

@@ -229,100 +229,11 @@ def test_relu_add_cat():
         ME.SparseTensor(coordinates=coords, features=x)  # CPU tensors: no CPU path
 
 
-@pytest.mark.parametrize("Cin,Cout", [(32, 32), (96, 96), (128, 96), (64, 128)])
-def test_center_fused_reduction_is_bit_identical(Cin, Cout):
-    """lidog_sconv_center_reduce (centre offset computed inside the reduction pass, gathered GEMM over the rule book
-    without its centre segment) against the two-pass path: forward with bias and BatchNorm statistics, data gradient
-    with an addend -- the same additions in the same order, so torch.equal"""
-    import lidog_amd.me as ME
-    from lidog_amd._lib import call, ptr, load
-    coords = _rand_coords(21, n=9000, extent=16)
-    _, sg = _maps(coords)
-    m = sg.coordinate_manager.kernel_map(1, 1, 3)
-    assert m.center == 13 and m.tiles_nc[2] == m.P - m.n_out
-    n = m.n_out
-    g = torch.Generator(device="cuda").manual_seed(Cin + Cout)
-    x = torch.randn(n, Cin, device="cuda", generator=g)
-    W = torch.randn(27, Cin, Cout, device="cuda", generator=g) * 0.1
-    bias = torch.randn(1, Cout, device="cuda", generator=g)
-    add = torch.randn(n, Cout, device="cuda", generator=g)
-    L = load()
-    # two-pass reference
-    T = torch.empty(m.P, Cout, device="cuda")
-    ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T, None)
-    rp, rl = m.rows("out")
-    ref = torch.empty(n, Cout, device="cuda")
-    sums_r = torch.empty(2 * Cout + 1, dtype=torch.float64, device="cuda")
-    ws = torch.empty(L.lidog_sconv_reduce_stats_ws(n, Cout), dtype=torch.float64, device="cuda")
-    call("lidog_sconv_reduce_rows_stats", ptr(T), ptr(rp), ptr(rl), n, Cout, ptr(bias), ptr(ref), ptr(sums_r), ptr(ws),
-         float(n), 0.0, 0.0, None, None, None, None)
-    ref_add = torch.empty(n, Cout, device="cuda")
-    call("lidog_sconv_reduce_rows", ptr(T), ptr(rp), ptr(rl), n, Cout, None, ptr(add), ptr(ref_add))
-    # fused
-    T2 = torch.full((m.P, Cout), float("nan"), device="cuda")     # the centre segment must never be read
-    ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T2, None, m.tiles_nc)
-    rpm, rlm = m.rows("out", True)
-    assert int((rlm[:m.P] == -1).sum()) == n
-    out = torch.empty(n, Cout, device="cuda")
-    sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device="cuda")
-    ws2 = torch.empty(L.lidog_sconv_center_reduce_ws(n, Cout), dtype=torch.float64, device="cuda")
-    call("lidog_sconv_center_reduce", ptr(x), ptr(W[13]), ptr(T2), ptr(rpm), ptr(rlm), n, Cin, Cout, ptr(bias), None,
-         ptr(out), ptr(sums), ptr(ws2), float(n), 0.0, 0.0, None, None, None, None)
-    assert torch.equal(out, ref)
-    torch.testing.assert_close(sums, sums_r, rtol=1e-12, atol=1e-9)
-    out_add = torch.empty(n, Cout, device="cuda")
-    call("lidog_sconv_center_reduce", ptr(x), ptr(W[13]), ptr(T2), ptr(rpm), ptr(rlm), n, Cin, Cout, None, ptr(add),
-         ptr(out_add), None, None, float(n), 0.0, 0.0, None, None, None, None)
-    assert torch.equal(out_add, ref_add)
-
-
 def test_coordinate_range_checked():
     import lidog_amd.me as ME
     coords = torch.tensor([[0, 0, 0, 0], [0, 70000, 0, 0]], dtype=torch.int32).cuda()
     with pytest.raises(ValueError):
         ME.SparseTensor(coordinates=coords, features=torch.ones(2, 1).cuda())
-
-
-@pytest.mark.parametrize("Cin,Cout,n", [(96, 96, 9000), (32, 64, 700), (128, 128, 9000), (64, 32, 3000)])
-def test_output_stationary_conv_equals_two_pass_and_oracle(Cin, Cout, n):
-    """csrc/sconv_os.hip (no product rows, no reduction pass; not used by lidog_amd.me, see its header): forward,
-    data gradient (through the symmetry of the stride-1 map) and BatchNorm partial sums, bit-identical to the
-    oracle's exact mode -- ragged last block, blocks without pairs for some offsets, padding rows."""
-    import oracle.me_cpu as OME
-    import lidog_amd.me as ME
-    from lidog_amd._lib import call, load, ptr
-    OME.set_mode("exact")
-    coords = _rand_coords(11, n=n, extent=16)
-    so, sg = _maps(coords)
-    N = coords.shape[0]
-    g = torch.Generator().manual_seed(Cin + Cout)
-    x = torch.randn(N, Cin, generator=g)
-    co = OME.MinkowskiConvolution(Cin, Cout, kernel_size=3, dimension=3)
-    xo = x.clone().requires_grad_(True)
-    yo = co(OME.SparseTensor(xo, coordinate_manager=so.coordinate_manager, coordinate_map_key=1))
-    gy = torch.randn(N, Cout, generator=g)
-    yo.F.backward(gy)
-    m = sg.coordinate_manager.kernel_map(1, 1, 3)
-    L = load()
-    BR = L.lidog_sconv_os_block_rows()
-    nb = (N + BR - 1) // BR
-    seg = torch.empty((m.K, nb + 1), dtype=torch.int32, device="cuda")
-    call("lidog_sconv_os_segments", ptr(m.pair_out), ptr(m.k_off), m.K, N, ptr(seg))
-    W = co.kernel.detach().cuda().contiguous()
-    out = torch.full((N, Cout), float("nan"), device="cuda")
-    part = torch.empty(nb * 2 * Cout, dtype=torch.float64, device="cuda")
-    call("lidog_sconv_os", ptr(x.cuda()), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, N, ptr(W), 0, Cin, Cout,
-         ptr(out), ptr(part))
-    assert torch.equal(out.cpu(), yo.F.detach())
-    sums = part.view(nb, 2 * Cout).sum(0).cpu()
-    d = yo.F.detach().double()
-    torch.testing.assert_close(sums[:Cout], d.sum(0), rtol=1e-12, atol=1e-9)
-    torch.testing.assert_close(sums[Cout:], (d * d).sum(0), rtol=1e-12, atol=1e-9)
-    Wt = W.transpose(1, 2).contiguous()
-    gx = torch.full((N, Cin), float("nan"), device="cuda")
-    call("lidog_sconv_os", ptr(gy.cuda()), ptr(m.pair_in), ptr(m.pair_out), ptr(seg), m.K, N, ptr(Wt), 1, Cout, Cin,
-         ptr(gx), None)
-    assert torch.equal(gx.cpu(), xo.grad)
 
 
 @pytest.mark.parametrize("C,mask", [(96, "from_x"), (96, "from_y"), (32, "none"), (256, "from_y"), (96, "bits"),

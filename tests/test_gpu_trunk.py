@@ -328,3 +328,17 @@ def test_executor_under_plain_data_parallel_fires_the_gradient_hooks():
             p.terminate()
             p.join(30)
     assert not failed, got
+
+
+def test_second_backward_over_one_executor_pass_is_refused():
+    """the executor reuses its activation arena once a pass has been backpropagated: a second backward over the same
+    graph must raise instead of reading activations a later forward may have overwritten"""
+    import lidog_amd.me as ME
+    model = _model()
+    b = _batch((65, 75))
+    sem, _ = model(ME.SparseTensor(coordinates=b["coords_int"], features=b["source_features0"]), is_train=True)
+    assert type(sem.F.grad_fn).__name__ == "_TrunkFnBackward"
+    loss = sem.F.square().mean()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already been backpropagated"):
+        loss.backward()

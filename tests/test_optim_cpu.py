@@ -150,3 +150,45 @@ def test_optimizer_runs_skip_parameters_without_gradient():
     runs = opt._runs()     # first two are at step 2, the others at step 1: two kernel launches
     n01 = params[0].numel() + params[1].numel()
     assert runs == [[0, n01, 2], [n01, opt.flat.total, 1]]
+
+
+@pytest.mark.parametrize("kind", ["Adam", "SGD"])
+def test_optimizer_state_interchanges_with_torch_optim(kind):
+    """Lightning stores torch.optim's own state layout in `optimizer_states` (trainer.fit(ckpt_path=...),
+    train_lidog.py:298-301).  The flat optimisers write that layout (checkpoint.save_lightning_checkpoint) and read it:
+    torch -> flat -> torch is the identity, a parameter that never got a gradient has no entry on either side."""
+    import copy
+    from lidog_amd.optim import FlatAdam, FlatSGD
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3))
+    twin = copy.deepcopy(net)
+    if kind == "Adam":
+        topt = torch.optim.Adam(twin.parameters(), lr=1e-2, weight_decay=1e-4)
+    else:
+        topt = torch.optim.SGD(twin.parameters(), lr=1e-2, momentum=0.98, weight_decay=1e-4, nesterov=True)
+    for it in range(3):     # the last layer never takes part: no gradient, no state
+        topt.zero_grad()
+        twin[1](twin[0](torch.randn(7, 6))).square().mean().backward()
+        topt.step()
+    sd = copy.deepcopy(topt.state_dict())
+    opt = (FlatAdam(net, lr=0.5, weight_decay=1e-4) if kind == "Adam" else FlatSGD(net, lr=0.5, weight_decay=1e-4))
+    opt.load_state_dict(sd)
+    assert opt.lr == 1e-2 and opt.param_steps == [3, 3, 3, 3, 0, 0]
+    names = ("exp_avg", "exp_avg_sq") if kind == "Adam" else ("momentum_buffer",)
+    for i, (p, off) in enumerate(zip(opt.flat.params, opt.flat.offsets)):
+        for k in names:
+            got = getattr(opt, k)[off:off + p.numel()].view(p.shape)
+            want = sd["state"][i][k] if i in sd["state"] else torch.zeros_like(p)
+            assert torch.equal(got, want), (i, k)
+    back = opt.torch_state_dict()
+    assert sorted(back["state"]) == sorted(sd["state"]) == [0, 1, 2, 3]
+    fresh = (torch.optim.Adam(twin.parameters(), lr=1.0) if kind == "Adam" else
+             torch.optim.SGD(twin.parameters(), lr=1.0, momentum=0.98, nesterov=True))
+    fresh.load_state_dict(back)            # torch accepts what we write
+    for i in back["state"]:
+        for k in names:
+            assert torch.equal(back["state"][i][k], sd["state"][i][k])
+        if kind == "Adam":
+            assert float(back["state"][i]["step"]) == float(sd["state"][i]["step"]) == 3.0
+    g = fresh.param_groups[0]
+    assert g["lr"] == 1e-2 and g["weight_decay"] == 1e-4 and back["param_groups"][0]["params"] == list(range(6))
