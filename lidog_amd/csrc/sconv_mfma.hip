@@ -231,6 +231,10 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] += bv[t];
+    // (Round 3 experiment: the 96-column case -- 3 dword stores at a 12-byte lane stride per accumulator register --
+    // staged through LDS and written as 1 KB-contiguous 16-byte stores instead: bit-identical, 0.25 ms per training step
+    // SLOWER (50.19 vs 49.95 ms, twice): the nontemporal dword stores already combine, the extra barrier and LDS hop do
+    // not pay.  Not kept.)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
