@@ -531,25 +531,39 @@ __global__ __launch_bounds__(256) void k_pairs_count(const int32_t *__restrict__
     if (threadIdx.x == 0) cnt[(int64_t)k * nbp + b] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// one thread per k: exclusive scan over row blocks, then (thread 0) over k -> k_off
-__global__ __launch_bounds__(128) void k_pairs_scan(int32_t *__restrict__ cnt, int nbp, int K,
-                                                    int64_t *__restrict__ k_off, int32_t *__restrict__ totals) {
-    const int k = threadIdx.x;
-    if (k < K) {
-        int run = 0;
-        for (int b = 0; b < nbp; ++b) {
-            int v = cnt[(int64_t)k * nbp + b];
-            cnt[(int64_t)k * nbp + b] = run;
-            run += v;
-        }
-        totals[k] = run;
-    }
+// one workgroup per offset k: exclusive scan of its row-block counts (chunks of 256 with a carry), total -> totals[k];
+// a second, one-wave launch turns the K totals into k_off.  (Round 2 had ONE thread per offset walk its nbp counts
+// serially: 84 us per map on the map stream, 0.95 ms per training step.)
+__global__ __launch_bounds__(256) void k_pairs_scan(int32_t *__restrict__ cnt, int nbp, int32_t *__restrict__ totals) {
+    const int k = blockIdx.x;
+    int32_t *c = cnt + (int64_t)k * nbp;
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    for (int b0 = 0; b0 < nbp; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nbp ? c[b] : 0;
+        int tot;
+        const int ex = block_excl_scan_256(v, &tot);
+        const int carry = carry_s;
+        if (b < nbp) c[b] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[k] = carry_s;
+}
+
+__global__ __launch_bounds__(128) void k_pairs_koff(const int32_t *__restrict__ totals, int K, int64_t *__restrict__ k_off) {
+    __shared__ int64_t s[128];
+    const int t = threadIdx.x;
+    s[t] = t < K ? totals[t] : 0;
+    __syncthreads();
+    if (t == 0) {
         int64_t run = 0;
         for (int kk = 0; kk < K; ++kk) {
             k_off[kk] = run;
-            run += totals[kk];
+            run += s[kk];
         }
         k_off[K] = run;
     }
@@ -613,7 +627,8 @@ extern "C" int lidog_kernel_map_pairs(const int32_t *nbr, int64_t n_out, int64_t
     int32_t *cnt = ws, *totals = ws + (int64_t)nbp * K;
     dim3 grid((unsigned)nbp, (unsigned)K);
     k_pairs_count<<<grid, 256, 0, st>>>(nbr, n_out, nbp, cnt);
-    k_pairs_scan<<<1, 128, 0, st>>>(cnt, nbp, K, k_off_dev, totals);
+    k_pairs_scan<<<(unsigned)K, 256, 0, st>>>(cnt, nbp, totals);
+    k_pairs_koff<<<1, 128, 0, st>>>(totals, K, k_off_dev);
     k_pairs_emit<<<grid, 256, 0, st>>>(nbr, n_out, n_in, nbp, cnt, k_off_dev, pair_in, pair_out, pos_out, pos_in);
     LIDOG_LAUNCH_CHECK();
     return 0;
