@@ -368,6 +368,26 @@ int lidog_comm_destroy(void *comm);
 int lidog_allreduce_f32(float *buf, int64_t n, void *comm, void *stream);
 int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *stream);
 
+/* One-shot peer all-reduce for the small SyncBatchNorm statistics messages (241 messages of
+ * <= 4 KB per step, all on the dependent chain): every rank pushes its vector into a mailbox in every peer's memory
+ * over its direct xGMI link, waits for the N senders of its own mailbox and adds them in rank order (same bits on
+ * every rank) -- one single-workgroup launch on the caller's stream instead of a ring / tree collective.
+ * Set-up: every rank allocates a mailbox (lidog_peer_mailbox_alloc: fine-grained device memory + its hipIpc handle of
+ * lidog_peer_handle_bytes() bytes), the handles travel through whatever the host has (torch.distributed here), every
+ * rank opens the others' (lidog_peer_mailbox_open) and builds the communicator.  Waits are bounded: lidog_peer_status
+ * != 0 means a sender's flag never arrived (the caller falls back to lidog_allreduce_f64). */
+int32_t lidog_peer_handle_bytes(void);
+int64_t lidog_peer_mailbox_bytes(int32_t nranks, int32_t max_doubles);
+int lidog_peer_mailbox_alloc(int64_t bytes, void **ptr_out, void *handle_out);
+int lidog_peer_mailbox_open(const void *handle, void **ptr_out);
+int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_doubles, void *local, void *const *peer_ptrs,
+                           void **comm_out);
+int32_t lidog_peer_max_doubles(void *comm);
+int lidog_peer_set_spin_limit(void *comm, int64_t polls /* ~1-2 us each; 0 = default, about a minute */);
+int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void *stream);
+int32_t lidog_peer_status(void *comm);
+int lidog_peer_comm_destroy(void *comm, int32_t close_peers);
+
 /* ------------------------------------------------------------------ host-side tables of a kernel map (csrc/hostprep.hip)
  * Pure host code.  k_off_host [K+1]: the rule book's offsets (lidog_kernel_map_pairs' k_off copied to the host).
  * lidog_tiles_host: the (tile_k, tile_row0, tile_rows) descriptors lidog_sconv_gemm takes, `tile_rows` (128) pairs per
@@ -422,7 +442,8 @@ int64_t lidog_wgrad_items_host(const int64_t *k_off_host, int32_t K, int64_t chu
  *   [6] number of buckets (0 = none), [7] int64 [n][2] element ranges (lo, hi) of the buckets in that buffer,
  *   [8] int32 [n] HOST countdown per bucket (gradients still missing; shared with the caller, who counts the
  *       parameters that are not the trunk's), [9] int32 [n_convs][4] HOST: bucket of (kernel, bias, BatchNorm weight,
- *       BatchNorm bias) of every convolution or -1.
+ *       BatchNorm bias) of every convolution or -1,
+ *   [10] peer all-reduce communicator (lidog_peer_comm_create) or 0: takes the statistics messages that fit its mailbox.
  * A bucket whose countdown reaches 0 inside lidog_trunk_backward is all-reduced (sum) on its stream behind events
  * recorded on `stream` and `lane`; the caller makes its optimiser step wait for that stream. */
 int lidog_trunk_forward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,

@@ -87,6 +87,16 @@ SIGNATURES = {
     "lidog_comm_destroy": [_p],
     "lidog_allreduce_f32": [_p, _i64, _p, _p],
     "lidog_allreduce_f64": [_p, _i64, _p, _p],
+    "lidog_peer_handle_bytes": [],
+    "lidog_peer_mailbox_bytes": [_i32, _i32],
+    "lidog_peer_mailbox_alloc": [_i64, ctypes.POINTER(ctypes.c_void_p), _p],
+    "lidog_peer_mailbox_open": [_p, ctypes.POINTER(ctypes.c_void_p)],
+    "lidog_peer_comm_create": [_i32, _i32, _i32, _p, _p, ctypes.POINTER(ctypes.c_void_p)],
+    "lidog_peer_max_doubles": [_p],
+    "lidog_peer_set_spin_limit": [_p, _i64],
+    "lidog_peer_allreduce_f64": [_p, _p, _i64, _p],
+    "lidog_peer_status": [_p],
+    "lidog_peer_comm_destroy": [_p, _i32],
     "lidog_tiles_host": [_p, _i32, _i32, _i32, _p, _i64],
     "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
     "lidog_trunk_fusions": [_i32],
@@ -99,7 +109,8 @@ SIGNATURES = {
 _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "lidog_bn_reduce_ws": _i64,
              "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
              "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64, "lidog_bitmap_words": _i64,
-             "lidog_bn_bwd_reduce_blocks": _i64, "lidog_relu_bits_words": _i64}
+             "lidog_bn_bwd_reduce_blocks": _i64, "lidog_relu_bits_words": _i64,
+             "lidog_peer_mailbox_bytes": _i64}
 
 _lib = None
 

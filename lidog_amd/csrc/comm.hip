@@ -97,3 +97,191 @@ extern "C" int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *str
     LIDOG_CHECK_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat64, ncclSum, (ncclComm_t)comm, (hipStream_t)stream));
     return 0;
 }
+
+// ------------------------------------------------------------------ one-shot peer all-reduce for small messages
+// The SyncBatchNorm statistics messages of the path (train_lidog.py:228) are <= 513 doubles, 241 of them per training
+// step, every one on the dependent chain: a ring / tree collective pays its hop latency 241 times.  xGMI gives every GPU
+// a direct link to every other one, so each rank PUSHES its vector into a mailbox in every peer's memory (one posted
+// write per peer), raises a per-sender flag behind it, waits for the flags of all senders in its own mailbox, and adds
+// the N vectors up in rank order -- the same order on every rank, so every rank computes the same bits.  One
+// workgroup, one launch, on the caller's stream.
+//
+// Mailbox of a rank (fine-grained device memory, opened by the peers through hipIpc handles):
+//   [2 slots][nranks][stride] doubles; a sender's data at [slot][sender][0 .. n), its flag (the call's sequence number,
+//   uint64) at [slot][sender][stride - 1].  Slots alternate with the sequence number: call k + 2 cannot start before
+//   every rank has contributed to call k + 1, i.e. has finished reading call k.
+// Waiting is bounded: a rank that does not see a flag within the limit sets the error word and leaves (the launch
+// always terminates); lidog_peer_status reports it.
+#define PEER_MAX_RANKS 16
+#define PEER_SPIN_LIMIT_DEFAULT (1u << 25)   // x ~1-2 us of sleep + system-scope load: about a minute
+
+struct PeerComm {
+    int rank, nranks, max_doubles, stride;
+    unsigned spin_limit;
+    uint64_t seq;
+    double *local;
+    double *peers[PEER_MAX_RANKS];
+    int32_t *err_dev;    // 0 ok, 1 = timed out waiting for a sender
+};
+
+struct PeerArgs {
+    double *peers[PEER_MAX_RANKS];
+    double *local;
+    int rank, nranks, stride;
+    unsigned spin_limit;
+    uint64_t seq;
+    int32_t *err;
+};
+
+__global__ __launch_bounds__(256) void k_peer_allreduce(PeerArgs a, double *__restrict__ buf, int n) {
+    const int slot = (int)(a.seq & 1);
+    const int tid = threadIdx.x;
+    // 1. push my vector into every rank's mailbox (my own included: the sum below reads all N the same way)
+    for (int idx = tid; idx < n * a.nranks; idx += 256) {
+        const int p = idx / n, i = idx - p * n;
+        double *dst = a.peers[p] + ((size_t)slot * a.nranks + a.rank) * a.stride;
+        __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();     // my stores are visible system-wide before any of my flags is
+    __syncthreads();
+    if (tid < a.nranks) {
+        uint64_t *flag = reinterpret_cast<uint64_t *>(a.peers[tid] + ((size_t)slot * a.nranks + a.rank) * a.stride +
+                                                      (a.stride - 1));
+        __hip_atomic_store(flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // 2. wait for sender `tid` in MY mailbox
+        const uint64_t *mine = reinterpret_cast<const uint64_t *>(
+            a.local + ((size_t)slot * a.nranks + tid) * a.stride + (a.stride - 1));
+        unsigned spins = 0;
+        while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            if (++spins > a.spin_limit) {
+                *a.err = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    // 3. the sum, in rank order
+    for (int i = tid; i < n; i += 256) {
+        double s = 0.0;
+        for (int r = 0; r < a.nranks; ++r) {
+            const double *src = a.local + ((size_t)slot * a.nranks + r) * a.stride;
+            s += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        buf[i] = s;
+    }
+}
+
+extern "C" int32_t lidog_peer_handle_bytes(void) { return (int32_t)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int64_t lidog_peer_mailbox_bytes(int32_t nranks, int32_t max_doubles) {
+    if (nranks < 1 || nranks > PEER_MAX_RANKS || max_doubles < 1) return -1;
+    const int64_t stride = ((int64_t)max_doubles + 1 + 15) / 16 * 16;     // data + flag, whole 128-byte lines per sender
+    return 2 * (int64_t)nranks * stride * 8;
+}
+
+// fine-grained (uncached, coherent across agents) device memory for a mailbox, zeroed; handle_out: its hipIpc handle
+extern "C" int lidog_peer_mailbox_alloc(int64_t bytes, void **ptr_out, void *handle_out) {
+    LIDOG_REQUIRE(bytes > 0 && ptr_out && handle_out, "peer_mailbox_alloc: bad arguments");
+    void *p = nullptr;
+    LIDOG_CHECK_HIP(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained));
+    LIDOG_CHECK_HIP(hipMemset(p, 0, (size_t)bytes));
+    LIDOG_CHECK_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    LIDOG_CHECK_HIP(hipIpcGetMemHandle(&h, p));
+    memcpy(handle_out, &h, sizeof(h));
+    *ptr_out = p;
+    return 0;
+}
+
+extern "C" int lidog_peer_mailbox_open(const void *handle, void **ptr_out) {
+    LIDOG_REQUIRE(handle && ptr_out, "peer_mailbox_open: bad arguments");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    LIDOG_CHECK_HIP(hipIpcOpenMemHandle(ptr_out, h, hipIpcMemLazyEnablePeerAccess));
+    // probe the mapping with a runtime copy before any kernel stores through it: a mapping that is not usable from
+    // this device shows up here as an error code instead of as a memory fault inside the all-reduce kernel
+    uint64_t probe = 0;
+    hipError_t e = hipMemcpy(&probe, *ptr_out, sizeof(probe), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void)hipIpcCloseMemHandle(*ptr_out);
+        *ptr_out = nullptr;
+        lidog_set_error("peer_mailbox_open: the peer's mailbox cannot be read from this device (%s)", hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+// peer_ptrs [nranks]: the mailbox of every rank as mapped into THIS process (entry `rank` = local)
+extern "C" int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_doubles, void *local,
+                                      void *const *peer_ptrs, void **comm_out) {
+    LIDOG_REQUIRE(nranks >= 1 && nranks <= PEER_MAX_RANKS && rank >= 0 && rank < nranks && local && peer_ptrs && comm_out,
+                  "peer_comm_create: bad arguments (at most %d ranks)", PEER_MAX_RANKS);
+    PeerComm *c = new PeerComm();
+    c->rank = rank;
+    c->nranks = nranks;
+    c->max_doubles = max_doubles;
+    c->stride = (int)(((int64_t)max_doubles + 1 + 15) / 16 * 16);
+    c->seq = 0;
+    c->spin_limit = PEER_SPIN_LIMIT_DEFAULT;
+    c->local = (double *)local;
+    for (int r = 0; r < nranks; ++r) c->peers[r] = (double *)peer_ptrs[r];
+    c->peers[rank] = c->local;
+    if (hipMalloc((void **)&c->err_dev, sizeof(int32_t)) != hipSuccess || hipMemset(c->err_dev, 0, sizeof(int32_t)) != hipSuccess) {
+        delete c;
+        lidog_set_error("peer_comm_create: cannot allocate the error word");
+        return 1;
+    }
+    *comm_out = c;
+    return 0;
+}
+
+extern "C" int32_t lidog_peer_max_doubles(void *comm) { return comm ? ((PeerComm *)comm)->max_doubles : 0; }
+
+// polls a waiting rank makes before it gives up on a sender (each ~1-2 us); 0 restores the default (about a minute)
+extern "C" int lidog_peer_set_spin_limit(void *comm, int64_t polls) {
+    LIDOG_REQUIRE(comm && polls >= 0 && polls < ((int64_t)1 << 32), "peer_set_spin_limit: bad arguments");
+    ((PeerComm *)comm)->spin_limit = polls ? (unsigned)polls : PEER_SPIN_LIMIT_DEFAULT;
+    return 0;
+}
+
+// sum over the ranks of buf[0 .. n) in place, identical bits on every rank; every rank calls it in the same order
+extern "C" int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void *stream) {
+    PeerComm *c = (PeerComm *)comm;
+    LIDOG_REQUIRE(c && buf && n >= 1 && n <= c->max_doubles, "peer_allreduce_f64: %lld doubles, the mailbox takes %d",
+                  (long long)n, c ? c->max_doubles : 0);
+    PeerArgs a;
+    for (int r = 0; r < c->nranks; ++r) a.peers[r] = c->peers[r];
+    a.local = c->local;
+    a.rank = c->rank;
+    a.nranks = c->nranks;
+    a.stride = c->stride;
+    a.seq = ++c->seq;
+    a.spin_limit = c->spin_limit;
+    a.err = c->err_dev;
+    k_peer_allreduce<<<1, 256, 0, (hipStream_t)stream>>>(a, buf, (int)n);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// 0 = every wait so far was satisfied, 1 = a sender's flag did not arrive in time (synchronises with the device)
+extern "C" int32_t lidog_peer_status(void *comm) {
+    PeerComm *c = (PeerComm *)comm;
+    if (!c) return -1;
+    int32_t e = -1;
+    if (hipMemcpy(&e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return e;
+}
+
+extern "C" int lidog_peer_comm_destroy(void *comm, int32_t close_peers) {
+    PeerComm *c = (PeerComm *)comm;
+    if (!c) return 0;
+    if (close_peers)
+        for (int r = 0; r < c->nranks; ++r)
+            if (r != c->rank && c->peers[r]) (void)hipIpcCloseMemHandle(c->peers[r]);
+    (void)hipFree(c->err_dev);
+    (void)hipFree(c->local);
+    delete c;
+    return 0;
+}

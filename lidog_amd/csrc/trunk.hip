@@ -74,7 +74,7 @@ inline T *P(int64_t v) { return reinterpret_cast<T *>(static_cast<uintptr_t>(v))
 // what 0 = all-reduce (sum) of b doubles at device address a, in order on the launch stream; 1 = gradient bucket a has
 // all its gradients queued.
 enum { DP_SYNC_BN, DP_COMM_BN, DP_CALLBACK, DP_COMM_GRAD, DP_COMM_STREAM, DP_GRAD_BASE, DP_N_BUCKETS, DP_BUCKETS,
-       DP_PENDING, DP_PARAM_BUCKET, DP_COLS = 12 };
+       DP_PENDING, DP_PARAM_BUCKET, DP_PEER, DP_COLS = 12 };
 typedef int (*dp_callback_t)(int32_t what, int64_t a, int64_t b);
 
 struct Dp {
@@ -83,7 +83,7 @@ struct Dp {
     bool buckets() const { return d && d[DP_N_BUCKETS] > 0 && d[DP_PENDING] && d[DP_PARAM_BUCKET]; }
     int check() const {
         if (!d) return 0;
-        LIDOG_REQUIRE(!d[DP_SYNC_BN] || d[DP_COMM_BN] || d[DP_CALLBACK],
+        LIDOG_REQUIRE(!d[DP_SYNC_BN] || d[DP_COMM_BN] || d[DP_CALLBACK] || d[DP_PEER],
                       "trunk: SyncBatchNorm statistics need a communicator or a callback");
         if (d[DP_N_BUCKETS] > 0) {
             LIDOG_REQUIRE(d[DP_BUCKETS] && d[DP_PENDING] && d[DP_PARAM_BUCKET], "trunk: gradient bucket tables missing");
@@ -94,7 +94,11 @@ struct Dp {
     }
     // sum over the ranks of n doubles, in order on `st`
     int allreduce_f64(double *buf, int64_t n, void *st) const {
+        // statistics messages: the one-shot peer all-reduce where it is set up (lidog_amd.comm), else the communicator
+        if (d[DP_PEER] && n <= lidog_peer_max_doubles(P<void>(d[DP_PEER])))
+            return lidog_peer_allreduce_f64(P<void>(d[DP_PEER]), buf, n, st);
         if (d[DP_COMM_BN]) return lidog_allreduce_f64(buf, n, P<void>(d[DP_COMM_BN]), st);
+        LIDOG_REQUIRE(d[DP_CALLBACK], "trunk: no transport for the statistics all-reduce");
         int rc = reinterpret_cast<dp_callback_t>(static_cast<uintptr_t>(d[DP_CALLBACK]))(0, (int64_t)(uintptr_t)buf, n);
         LIDOG_REQUIRE(rc == 0, "trunk: the statistics all-reduce callback failed (%d)", rc);
         return 0;

@@ -357,7 +357,7 @@ def _build_tables(prog, x, run):
 
 DP_COLS = 12
 (DP_SYNC_BN, DP_COMM_BN, DP_CALLBACK, DP_COMM_GRAD, DP_COMM_STREAM, DP_GRAD_BASE, DP_N_BUCKETS, DP_BUCKETS, DP_PENDING,
- DP_PARAM_BUCKET) = range(10)
+ DP_PARAM_BUCKET, DP_PEER) = range(11)
 _CALLBACK_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64)
 
 
@@ -378,6 +378,8 @@ class _Collectives:
             self.desc[DP_SYNC_BN] = 1
             if self.tr.kind == "native":
                 self.desc[DP_COMM_BN] = self.tr.comm_bn
+            if self.tr.peer:
+                self.desc[DP_PEER] = self.tr.peer
         self.regions = ()         # the tensors the statistics messages live in (set per call)
         self.buckets = None
 

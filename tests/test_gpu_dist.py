@@ -220,3 +220,71 @@ def test_executor_with_rccl_collectives_equals_the_operator_path():
     p.join(120)
     assert ok, msg
     assert p.exitcode == 0
+
+
+def _peer_worker(rank, world, port, q):
+    import traceback
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIDOG_PEER_ALLREDUCE="1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, REPO)
+        torch.cuda.set_device(0)
+        from lidog_amd import _lib, comm
+        tr = comm.transport()
+        if tr.peer is None:
+            q.put((rank, False, "peer all-reduce not available: " + tr.peer_note))
+            dist.barrier()
+            return
+        g = torch.Generator().manual_seed(7)
+        a = torch.randn(4096, 4096, device="cuda")
+        ok, msg = True, ""
+        for it in range(300):
+            n = [1, 65, 193, 513, 1026][it % 5]
+            # every rank can rebuild every rank's contribution: the expected result is the rank-ordered float64 sum
+            parts = [torch.randn(n, generator=torch.Generator().manual_seed(1000 * it + r), dtype=torch.float64) * 10 ** (r - 1)
+                     for r in range(world)]
+            want = parts[0].clone()
+            for r in range(1, world):
+                want = want + parts[r]
+            t = parts[rank].cuda()
+            if it % 7 == 0:
+                torch.mm(a, a)            # the kernel also has to get through behind a busy stream
+            tr.allreduce_f64(t)
+            if not torch.equal(t.cpu(), want):
+                ok, msg = False, f"call {it} (n = {n}): max |diff| {(t.cpu() - want).abs().max().item():.3e}"
+                break
+        if ok and _lib.load().lidog_peer_status(tr.peer) != 0:
+            ok, msg = False, "a wait timed out"
+        # bigger than the mailbox: falls back to the group's own all-reduce
+        big = torch.full((5000,), float(rank + 1), dtype=torch.float64, device="cuda")
+        tr.allreduce_f64(big)
+        if ok and not torch.equal(big.cpu(), torch.full((5000,), float(sum(range(1, world + 1))), dtype=torch.float64)):
+            ok, msg = False, "fallback for large messages"
+        q.put((rank, ok, msg))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, False, f"{e!r}\n{traceback.format_exc()}"))
+        raise
+
+
+def test_peer_allreduce_three_processes_one_gpu():
+    """The one-shot peer all-reduce of the SyncBatchNorm statistics messages (csrc/comm.hip: mailboxes opened through
+    hipIpc, push + flag + rank-ordered sum) with three processes sharing the one GPU: 300 calls of five message sizes,
+    every rank must hold exactly the rank-ordered float64 sum (identical bits on all ranks), no wait may time out.
+    What one GPU cannot show is the xGMI memory model between devices: on a multi-GPU node the start-up self-test of
+    lidog_amd.comm decides, and RCCL stays the fallback."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 2000
+    procs = [ctx.Process(target=_peer_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(3)]
+    failed = not all(ok for _, ok, _ in got)
+    for p in procs:
+        p.join(10 if failed else 60)
+        if p.is_alive():
+            p.terminate()
+            p.join(30)
+    assert not failed, got

@@ -253,6 +253,8 @@ def _dp_worker_body(rank, world, port, q, executor):
     # (here through the host callback into torch.distributed: gloo), unless the executor is switched off
     took = type(sem.F.grad_fn).__name__
     assert (took == "_TrunkFnBackward") == executor, took
+    from lidog_amd.comm import transport
+    peer_note = transport().peer_note         # "on": the statistics went through the one-shot peer all-reduce
     opt.zero_grad()
     total.backward()
     opt._prepare()                           # joins the lane, waits for the buckets: flat.grad = SUM over ranks
@@ -308,6 +310,8 @@ def _dp_worker_body(rank, world, port, q, executor):
             ok, msg = False, msg + f" gradient cosine {worst} at {wn}"
         if early < 1:
             ok, msg = False, msg + " no gradient bucket was reduced during backward"
+        if peer_note != "on":
+            ok, msg = False, msg + f" peer all-reduce: {peer_note}"
     q.put((rank, ok, msg))
     dist.barrier()
     dist.destroy_process_group()
