@@ -309,7 +309,10 @@ def main():
                "blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in blocks], "loss": loss}
         if world > 1 or single_dp:
             from lidog_amd.comm import transport
+            transport().check()
             res["config"]["collectives"] = transport().kind     # native = this library's RCCL communicators
+            res["config"]["statistics_allreduce"] = "peer one-shot" if transport().peer else \
+                f"{transport().kind} ({transport().peer_note})"
             res["config"]["trunk_path"] = "executor" if getattr(step, "last_path", "") == "_TrunkFnBackward" else \
                 getattr(step, "last_path", "unknown")
         if eval_rate is not None:

@@ -83,6 +83,13 @@ class Transport:
         else:
             dist.all_reduce(t, group=self.group)
 
+    def check(self):
+        """raise if a wait of the peer all-reduce ever timed out (synchronises with the device: call it at epoch / run
+        boundaries, not per step)"""
+        if self.peer is not None and _lib.load().lidog_peer_status(self.peer) != 0:
+            raise RuntimeError("lidog_amd.comm: a rank's statistics message did not arrive within the wait limit of the "
+                               "peer all-reduce; results since then are invalid (LIDOG_PEER_ALLREDUCE=0 uses RCCL only)")
+
     # ---- one-shot peer all-reduce of the statistics messages (csrc/comm.hip)
     PEER_MAX_DOUBLES = 2 * (2 * 256 + 1)     # the joint conv1 + downsample message of a 256-channel block
 

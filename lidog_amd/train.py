@@ -208,6 +208,10 @@ class Fit:
                    "losses": [float(l) for l in losses]}
             if self.val_data is not None and (epoch + 1) % self.check_val == 0:
                 rec["validation"] = self.validate(epoch)
+            if dist.is_available() and dist.is_initialized():
+                from .comm import _TRANSPORTS
+                for tr in _TRANSPORTS.values():                 # a statistics message that never arrived invalidates the epoch
+                    tr.check()
             rec["checkpoint"] = self.save(epoch)                # every_n_epochs=1, save_top_k=-1
             self.history.append(rec)
             self.log({k: v for k, v in rec.items() if k != "losses"})
