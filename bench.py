@@ -30,7 +30,9 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak = vector fp32 peak (MI355X_MICROARCH.md, Matrix cores)
-PMC_TRAFFIC_FILE = "r02_pmc_traffic_gemm.json"   # scripts/profile_round.sh writes it (FETCH_SIZE / WRITE_SIZE passes)
+# scripts/profile_round.sh <tag> writes profiles/<tag>_pmc_traffic_sconv_gemm_mfma.json (FETCH_SIZE / WRITE_SIZE passes)
+PMC_TRAFFIC_TAG = "r03_c"
+PMC_TRAFFIC_FILE = f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_gemm_mfma.json"
 
 
 def parse():
@@ -332,8 +334,9 @@ def main():
             # next to it (algorithmic bytes / launch time against 8 TB/s, and the PMC-measured traffic).
             res["roofline"] = {"bound": "mfma", "achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tfl / FP32_PEAK_TFLOPS, "traffic": traffic,
-                               "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc passes of this build, "
-                                                 "not collected by this run)" if traffic is not None else None,
+                               "traffic_source": f"profiles/{PMC_TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                 f"over the {PMC_TRAFFIC_TAG} build (the gathered GEMM is unchanged "
+                                                 "since), not collected by this run" if traffic is not None else None,
                                "kernel": "k_sconv_gemm_mfma (gathered GEMM of the sparse convolutions, f32 MFMA)",
                                "algorithmic_flops_per_launch": s["flops"] / s["launches"],
                                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
