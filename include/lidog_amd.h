@@ -190,7 +190,8 @@ int lidog_transpose_batched(const float *src, float *dst, const int64_t *desc, i
  * (nn.BatchNorm2d of utils/models/conv2d.py:18,21). */
 
 /* per-channel sums in double: sums[0..2C) = (sum x, sum x^2), overwritten.  ws: lidog_bn_reduce_ws(C, hw) doubles of
- * scratch (per-workgroup partials added in a fixed order; 0 = not needed, ws may be NULL).
+ * scratch -- for NCHW input (hw > 1) that many PER IMAGE (n x) -- holding per-workgroup partials that are added in a
+ * fixed order: no atomics anywhere, every sum is run-to-run reproducible (0 = not needed, ws may be NULL).
  * count > 0: also stored at sums[2*C] (SyncBatchNorm all-reduces the row count together with the sums).
  * mean != NULL: lidog_bn_finalize(sums, count, ...) is folded into the same launch (local BatchNorm). */
 int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw);

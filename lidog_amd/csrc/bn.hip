@@ -21,8 +21,6 @@ __device__ __forceinline__ void red_terms(float x, float dy, float ry, bool has_
     }
 }
 
-__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
-
 // rw / rb (MODE 1, ry == NULL): BatchNorm weight and bias -- the ReLU mask is then recomputed from x with the forward
 // pass's own expression ((x - mean) * invstd * w + b > 0, same operation order, contraction off: the same bits)
 // instead of being read from the saved output: one tensor less to stream for a BatchNorm + ReLU without residual
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(256) void k_colreduce_plane(const float *__restrict
                                                          const float *__restrict__ ry, int64_t hw, int C,
                                                          const float *__restrict__ mean,
                                                          const float *__restrict__ invstd,
-                                                         double *__restrict__ sums) {
+                                                         double *__restrict__ partial) {
     __shared__ double red[2][4];
     const int64_t plane = blockIdx.x;
     const int c = (int)(plane % C);
@@ -206,8 +204,11 @@ __global__ __launch_bounds__(256) void k_colreduce_plane(const float *__restrict
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = t0; red[1][threadIdx.x >> 6] = t1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomic_add_f64(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomic_add_f64(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        // one partial row per (image, chunk), two columns per channel: added in a fixed order by k_sums_finish -- no
+        // atomics (round 2 added these with fp64 atomics: the only run-to-run irreproducible sums left on the path)
+        double *row = partial + ((size_t)(plane / C) * gridDim.y + blockIdx.y) * 2 * C;
+        row[c] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        row[C + c] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -234,13 +235,14 @@ __global__ __launch_bounds__(256) void k_colreduce_strided(const float *__restri
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = t0; red[1][threadIdx.x >> 6] = t1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomic_add_f64(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomic_add_f64(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        sums[c] = red[0][0] + red[0][1] + red[0][2] + red[0][3];          // the only workgroup of this channel
+        sums[C + c] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
 static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4 == 0 && C / 4 <= 256; }
 #define COLREDUCE_MAX_BLOCKS 512
+#define COLREDUCE_PLANE_CHUNKS 64   // chunks of an NCHW plane (one workgroup each)
 // The backward reduction over [rows, C] takes the grid of the per-row convolution reductions (one row per thread until
 // 2048 workgroups are reached, then a grid-stride loop): the data-gradient reduction that produces dy can then
 // accumulate the same partials in its epilogue, bit for bit (sconv.hip:k_sconv_reduce_rows4_bwdstats)
@@ -288,28 +290,32 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
     } else {
         LIDOG_REQUIRE(rw == nullptr && rbits == nullptr,
                       "bn reduce: ReLU masks from x or from a bit mask only for [rows, C] with C %% 4 == 0");
-        // atomic variants accumulate: start from zero
-        if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st) != hipSuccess) return 1;
         if (hw == 1) {
+            // one workgroup per channel stores its result
             k_colreduce_strided<MODE><<<(unsigned)C, 256, 0, st>>>(x, dy, ry, n, C, mean, invstd, sums);
+            if (count > 0 || fin.mean || fin.dw || fin.db)
+                k_sums_post<<<(C + 127) / 128, 128, 0, st>>>(sums, C, count, fin);
         } else {
-            // n = number of images B; planes = B*C
+            // n = number of images B; planes = B*C; (image, chunk) partial rows summed in order by the finishing kernel
+            LIDOG_REQUIRE(ws != nullptr, "bn reduce: NCHW input needs a workspace of n * lidog_bn_reduce_ws() doubles");
             int64_t planes = n * C;
             int chunks = (int)cdiv64(hw, 16384);
             if (chunks < 1) chunks = 1;
-            if (chunks > 64) chunks = 64;
+            if (chunks > COLREDUCE_PLANE_CHUNKS) chunks = COLREDUCE_PLANE_CHUNKS;
             k_colreduce_plane<MODE><<<dim3((unsigned)planes, (unsigned)chunks), 256, 0, st>>>(x, dy, ry, hw, C, mean,
-                                                                                              invstd, sums);
+                                                                                              invstd, ws);
+            lidog_launch_sums_finish(ws, (int)(n * chunks), C, sums, count, fin, st);
         }
-        if (count > 0 || fin.mean || fin.dw || fin.db)
-            k_sums_post<<<(C + 127) / 128, 128, 0, st>>>(sums, C, count, fin);
     }
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
 
+// doubles of workspace: [rows, C] with C % 4 == 0: the table of per-workgroup partials; NCHW (hw > 1): PER IMAGE
+// (multiply by the number of images); 0 otherwise
 extern "C" int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw) {
-    return colreduce_uses_partials(C, hw) ? (int64_t)COLREDUCE_BWD_MAX_BLOCKS * 2 * C : 0;
+    if (colreduce_uses_partials(C, hw)) return (int64_t)COLREDUCE_BWD_MAX_BLOCKS * 2 * C;
+    return hw > 1 ? (int64_t)COLREDUCE_PLANE_CHUNKS * 2 * C : 0;
 }
 
 extern "C" int lidog_bn_stats(const float *x, int64_t n, int32_t C, int64_t hw, double *sums, double *ws, double count,

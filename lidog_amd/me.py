@@ -881,9 +881,9 @@ class _SparseConvFn(torch.autograd.Function):
         return gx, gW, gb, None, None, None, None, None, None
 
 
-def _bn_ws(C, hw, dev):
-    """scratch of the BatchNorm reductions (per-workgroup partials)"""
-    n = _lib.load().lidog_bn_reduce_ws(C, hw)
+def _bn_ws(C, hw, dev, images=1):
+    """scratch of the BatchNorm reductions (per-workgroup partials; NCHW input: per image)"""
+    n = _lib.load().lidog_bn_reduce_ws(C, hw) * (images if hw > 1 else 1)
     return torch.empty(n, dtype=torch.float64, device=dev) if n else None
 
 
@@ -930,12 +930,12 @@ class _BatchNormFn(torch.autograd.Function):
             if sums is None:
                 sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
                 if sync:
-                    call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)), rows, 0.0, 0.0,
+                    call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev, n)), rows, 0.0, 0.0,
                          None, None, None, None)
                 else:
                     mean = torch.empty(C, dtype=torch.float32, device=dev)
                     invstd = torch.empty(C, dtype=torch.float32, device=dev)
-                    call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev)), rows, float(eps),
+                    call("lidog_bn_stats", ptr(x), n, C, hw, ptr(sums), ptr(_bn_ws(C, hw, dev, n)), rows, float(eps),
                          float(momentum), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var))
             if sync:
                 if not presynced:
@@ -979,7 +979,7 @@ class _BatchNormFn(torch.autograd.Function):
         dw = dw if dw is not None else torch.empty(C, dtype=torch.float32, device=dev)
         db = db if db is not None else torch.empty(C, dtype=torch.float32, device=dev)
         call("lidog_bn_bwd_reduce", ptr(dy), ptr(x), ptr(y), n, C, hw, ptr(mean), ptr(invstd), ptr(sums),
-             ptr(_bn_ws(C, hw, dev)), rows, ptr(dw), ptr(db), ptr(mask_w), ptr(mask_b))
+             ptr(_bn_ws(C, hw, dev, n)), rows, ptr(dw), ptr(db), ptr(mask_w), ptr(mask_b))
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         count = rows

@@ -200,3 +200,39 @@ def test_highres_stress_forward():
     assert torch.isfinite(sem.F).all() and torch.isfinite(bev["block8"]).all()
     (sem.F.square().mean() + bev["block8"].square().mean()).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_bev_head_gradients_are_run_to_run_identical():
+    """Encoder2D on the B = 50 m image of two 120 k-point scans, twice: logits, every parameter gradient, the feature
+    gradient and the running statistics must be torch.equal between the runs -- no sum on the path depends on the order
+    in which workgroups finish (round 3: the BatchNorm2d plane sums are per-(image, chunk) partials added in a fixed
+    order; they were fp64 atomics in round 2)"""
+    import lidog_amd.me as ME
+    from lidog_amd import bev
+    st, _ = _tensor("kitti120k", [7, 8])
+    n = st.F.shape[0]
+    torch.manual_seed(5)
+    enc = bev.Encoder2D(96, 7).cuda().train()
+    sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
+    g = torch.Generator(device="cuda").manual_seed(2)
+    base = torch.rand(n, 96, device="cuda", generator=g)
+    gl = None
+    runs = []
+    for _ in range(2):
+        enc.load_state_dict(sd0)
+        enc.zero_grad()
+        feats = base.clone().requires_grad_(True)
+        img = bev.sparse2super(ME.SparseTensor(feats, coordinate_manager=st.coordinate_manager, coordinate_map_key=1), 50.0)
+        logits = enc(img)
+        if gl is None:
+            gl = torch.randn(logits.shape, device="cuda", generator=g)
+        logits.backward(gl)
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), feats.grad.clone(), {k: p.grad.clone() for k, p in enc.named_parameters()},
+                     {k: v.clone() for k, v in enc.state_dict().items()}))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
