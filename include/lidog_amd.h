@@ -384,7 +384,7 @@ int lidog_peer_mailbox_open(const void *handle, void **ptr_out);
 int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_doubles, void *local, void *const *peer_ptrs,
                            void **comm_out);
 int32_t lidog_peer_max_doubles(void *comm);
-int lidog_peer_set_spin_limit(void *comm, int64_t polls /* ~1-2 us each; 0 = default, about a minute */);
+int lidog_peer_set_spin_limit(void *comm, int64_t polls /* ~1-2 us each; 0 = default, several minutes */);
 int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void *stream);
 int32_t lidog_peer_status(void *comm);
 int lidog_peer_comm_destroy(void *comm, int32_t close_peers);

@@ -110,10 +110,11 @@ extern "C" int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *str
 //   [2 slots][nranks][stride] doubles; a sender's data at [slot][sender][0 .. n), its flag (the call's sequence number,
 //   uint64) at [slot][sender][stride - 1].  Slots alternate with the sequence number: call k + 2 cannot start before
 //   every rank has contributed to call k + 1, i.e. has finished reading call k.
-// Waiting is bounded: a rank that does not see a flag within the limit sets the error word and leaves (the launch
-// always terminates); lidog_peer_status reports it.
+// Waiting is bounded: a rank that does not see a flag within the limit (minutes by default, seconds in the start-up
+// self-test of lidog_amd.comm) sets the error word and leaves (the launch always terminates); lidog_peer_status reports it.
 #define PEER_MAX_RANKS 16
-#define PEER_SPIN_LIMIT_DEFAULT (1u << 25)   // x ~1-2 us of sleep + system-scope load: about a minute
+#define PEER_SPIN_LIMIT_DEFAULT (1u << 27)   // x ~1-2 us of sleep + system-scope load: several minutes (a rank may be
+                                            // busy writing a checkpoint while the others wait for its message)
 
 struct PeerComm {
     int rank, nranks, max_doubles, stride;
