@@ -94,3 +94,27 @@ def evaluate(model, batches, num_classes=7, ignore_label=-1):
             sel = coords[:, 0] == s
             rows.append(per_class_iou(preds[sel], labels[sel], num_classes, ignore_label))
     return mean_iou(torch.stack(rows))
+
+
+def write_results_csv(save_dir, source_names, target_name, per_scan_iou, class_names, first_target=True):
+    """The result file of test_epoch_end (utils/pipelines/trainer_lighting_bev.py:325-383):
+    `<save_dir>/results/<source>-TO-<target>.csv`, appended; header `source,target,<class names>,mean` before the first
+    target's row; per-class IoU = nan-mean over scans (-1 = class absent from the scan) x 100, rounded to 2 decimals with a
+    decimal COMMA, last column the nan-mean over classes.  `per_scan_iou`: [n_scans, C] as returned by per_class_iou;
+    `class_names`: the C names (the reference takes `training_dataset.class2names[1:]`).  Returns the path."""
+    import csv
+    import os
+    import numpy as np
+    os.makedirs(os.path.join(save_dir, "results"), exist_ok=True)
+    path = os.path.join(save_dir, "results", f"{source_names}-TO-{target_name}.csv")
+    x = per_scan_iou.detach().double().cpu().numpy().copy()
+    x[x == -1] = np.nan
+    per_class = np.nanmean(x, axis=0) * 100
+    average = np.nanmean(per_class, axis=0)
+    with open(path, "a") as f:
+        w = csv.writer(f)
+        if first_target:
+            w.writerow(["source", "target"] + list(class_names) + ["mean"])
+        w.writerow([source_names, target_name] + [str(round(p, 2)).replace(".", ",") for p in per_class] +
+                   [str(round(float(average), 2)).replace(".", ",")])
+    return path

@@ -362,3 +362,19 @@ def test_synth_matches_baseline_counts():
     assert synth.stride_counts(vox) == synth.BASELINE_COUNTS["nusc35k+mix3d"]
     pts, _ = synth.scan_points(0, **synth.CONFIGS["kitti120k"])
     assert pts.shape[0] == 120000
+
+
+def test_results_csv_has_the_reference_format(tmp_path):
+    """test_epoch_end's CSV (trainer_lighting_bev.py:325-383): header once, decimal commas, nan-mean over scans x 100"""
+    import csv
+    from lidog_amd.evaluate import write_results_csv
+    iou = torch.tensor([[0.5, -1.0, 0.25], [0.7, 0.1, -1.0]], dtype=torch.float64)
+    names = ["vehicle", "person", "road"]
+    p = write_results_csv(str(tmp_path), "SemanticKITTI", "NuScenes", iou, names)
+    write_results_csv(str(tmp_path), "SemanticKITTI", "SemanticPOSS", iou * 0 + 0.123456, names, first_target=False)
+    rows = list(csv.reader(open(p)))
+    assert p.endswith("results/SemanticKITTI-TO-NuScenes.csv")
+    assert rows[0] == ["source", "target", "vehicle", "person", "road", "mean"]
+    assert rows[1] == ["SemanticKITTI", "NuScenes", "60,0", "10,0", "25,0", "31,67"]
+    other = list(csv.reader(open(str(tmp_path / "results" / "SemanticKITTI-TO-SemanticPOSS.csv"))))
+    assert other == [["SemanticKITTI", "SemanticPOSS", "12,35", "12,35", "12,35", "12,35"]]
