@@ -113,7 +113,7 @@ def test_minkunet34bev_matches_reference_golden():
             # Gradients.  The head of the backward pass (final conv) is compared tightly.  Deeper down, a
             # ReLU whose pre-activation sits within fp32 noise of 0 can take the other branch than in the
             # golden run; each such flip changes that element's gradient by O(1) and everything upstream
-            # inherits it.  scripts/debug_layers.py shows the signature (all of block8 + the BEV head agree to
+            # inherits it.  a layer-by-layer comparison shows the signature (all of block8 + the BEV head agree to
             # 1e-6, then a step at one BN); the oracle itself moves by 6e-3 (vector-relative) between its
             # two summation orders.  So: tight where no ReLU lies in between, statistical below.
             rel = []
