@@ -1378,10 +1378,28 @@ class BasicBlock(nn.Module):
 
 
 class Bottleneck(nn.Module):
+    """ME's Bottleneck (1x1 -> 3^3 -> 1x1 x expansion, residual; imported by utils/models/minkunet_bev.py:4 and
+    selectable as `BLOCK` of a MinkUNet variant, never instantiated by the LiDOG configurations): the same fused
+    conv + BatchNorm (+ residual) + ReLU kernels as BasicBlock."""
     expansion = 4
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("Bottleneck is imported but never instantiated by the LiDOG hot path")
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=-1):
+        super().__init__()
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=1, dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                          dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv3 = MinkowskiConvolution(planes, planes * self.expansion, kernel_size=1, dimension=dimension)
+        self.norm3 = MinkowskiBatchNorm(planes * self.expansion, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = conv_bn(self.conv1, self.norm1, x, relu=True)
+        out = conv_bn(self.conv2, self.norm2, out, relu=True)
+        residual = x if self.downsample is None else self.downsample(x)
+        return conv_bn(self.conv3, self.norm3, out, relu=True, residual=residual)
 
 
 modules = types.ModuleType(__name__ + ".modules")

@@ -444,10 +444,30 @@ class BasicBlock(nn.Module):
 
 
 class Bottleneck(nn.Module):
+    """ME's Bottleneck block (structure evidenced in the reference by utils/models/resnet_block.py:59-117)."""
     expansion = 4
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("Bottleneck is imported but never instantiated by the LiDOG hot path")
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=-1):
+        super().__init__()
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=1, dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                          dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv3 = MinkowskiConvolution(planes, planes * self.expansion, kernel_size=1, dimension=dimension)
+        self.norm3 = MinkowskiBatchNorm(planes * self.expansion, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        residual = x
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.relu(self.norm2(self.conv2(out)))
+        out = self.norm3(self.conv3(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out += residual
+        return self.relu(out)
 
 
 modules = types.ModuleType(__name__ + ".modules")

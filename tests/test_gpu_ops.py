@@ -307,3 +307,35 @@ def test_reduction_with_batchnorm_backward_statistics_in_its_epilogue(C, mask):
         xh = ((pre - mean) * invstd).double()
         ref = torch.cat([gm.sum(0), (gm * xh).sum(0)])
         torch.testing.assert_close(sums_b[:2 * C], ref, rtol=1e-9, atol=1e-7)
+
+
+def test_bottleneck_block_matches_the_oracle():
+    """ME.modules.resnet_block.Bottleneck (imported by minkunet_bev.py:4; 1x1 -> 3^3 -> 1x1 x 4 + residual through a
+    1x1 downsample): forward and every parameter gradient against the oracle's block, training-mode BatchNorm"""
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    OME.set_mode("exact")
+    coords = _rand_coords(17, n=5000, extent=14)
+    so, sg = _maps(coords)
+    n = coords.shape[0]
+    torch.manual_seed(4)
+    down_o = torch.nn.Sequential(OME.MinkowskiConvolution(32, 64, kernel_size=1, dimension=3), OME.MinkowskiBatchNorm(64))
+    blk_o = OME.modules.resnet_block.Bottleneck(32, 16, downsample=down_o, dimension=3).train()
+    down_g = torch.nn.Sequential(ME.MinkowskiConvolution(32, 64, kernel_size=1, dimension=3), ME.MinkowskiBatchNorm(64))
+    blk_g = ME.modules.resnet_block.Bottleneck(32, 16, downsample=down_g, dimension=3)
+    assert list(blk_g.state_dict().keys()) == list(blk_o.state_dict().keys())
+    blk_g.load_state_dict(blk_o.state_dict())
+    blk_g.cuda().train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, 32, generator=g)
+    gy = torch.randn(n, 64, generator=g)
+    xo, xg = x.clone().requires_grad_(True), x.clone().cuda().requires_grad_(True)
+    yo = blk_o(OME.SparseTensor(xo, coordinate_manager=so.coordinate_manager, coordinate_map_key=1))
+    yg = blk_g(ME.SparseTensor(xg, coordinate_manager=sg.coordinate_manager, coordinate_map_key=1))
+    assert (yo.F.detach() - yg.F.detach().cpu()).abs().max().item() <= 2e-5
+    yo.F.backward(gy)
+    yg.F.backward(gy.cuda())
+    assert (xo.grad - xg.grad.cpu()).abs().max().item() <= 2e-5 * xo.grad.abs().max().item() + 1e-7
+    for (k, po), (_, pg) in zip(blk_o.named_parameters(), blk_g.named_parameters()):
+        a, b = pg.grad.cpu().double().flatten(), po.grad.double().flatten()
+        assert float((a - b).norm() / (b.norm() + 1e-30)) <= 1e-4, k
