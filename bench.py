@@ -282,6 +282,21 @@ def main():
     dt = ordered[len(ordered) // 2]           # median block (the slower of the middle two for an even count)
     total_timed_steps = args.steps * len(blocks)
     loss = float(out["loss"])
+    # data-parallel invariant: after any number of steps every rank holds the same parameters and the same BatchNorm
+    # running statistics (identical start, identical all-reduced gradients and statistics).  Checked bit for bit over
+    # the ranks -- a collective that misbehaved (lost bucket, stale statistics message) shows up here.
+    replicas_identical = None
+    if world > 1 or single_dp:
+        flat = step.opt.flat.flat
+        # the two BatchNorm2d of Encoder2D keep per-rank running statistics (they are not SyncBatchNorm in the reference
+        # either, train_lidog.py:228 converts the Minkowski ones only): not part of the invariant
+        stats = torch.cat([b.detach().double().flatten() for n, b in model.named_buffers()
+                           if "running" in n and not n.startswith("encoders2d")])
+        digest = torch.stack([flat.double().sum(), flat.double().abs().sum(), stats.sum(), stats.abs().sum()])
+        gathered = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        replicas_identical = {"parameters": all(bool(torch.equal(g[:2], gathered[0][:2])) for g in gathered),
+                              "syncbn_running_statistics": all(bool(torch.equal(g[2:], gathered[0][2:])) for g in gathered)}
     eval_rate = None
     if world == 1:
         # secondary figure: forward-only validation path, is_train=False, same batches
@@ -317,6 +332,7 @@ def main():
                 f"{transport().kind} ({transport().peer_note})"
             res["config"]["trunk_path"] = "executor" if getattr(step, "last_path", "") == "_TrunkFnBackward" else \
                 getattr(step, "last_path", "unknown")
+            res["replicas_identical"] = replicas_identical   # parameters + running statistics equal on every rank
         if eval_rate is not None:
             res["forward_only_scans_per_s"] = eval_rate
         s = timer.summary()

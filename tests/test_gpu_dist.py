@@ -288,3 +288,23 @@ def test_peer_allreduce_three_processes_one_gpu():
             p.terminate()
             p.join(30)
     assert not failed, got
+
+
+def test_two_rank_bench_keeps_replicas_identical():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank) with both ranks on the
+    one GPU over gloo (LIDOG_BENCH_ONE_GPU=1): the JSON line comes out, the ranks ran the executor with the peer
+    all-reduce for the statistics, and after the steps every rank holds bit-identical parameters and SyncBatchNorm
+    running statistics (the data-parallel invariant; bench.py checks it over the ranks)"""
+    import json
+    import subprocess
+    env = dict(os.environ, LIDOG_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29100 + os.getpid() % 800
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--min-seconds", "0.1", "--batch", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2+syncbn" and line["config"]["global_batch"] == 4
+    assert line["config"]["trunk_path"] == "executor" and line["config"]["statistics_allreduce"] == "peer one-shot"
+    assert line["replicas_identical"] == {"parameters": True, "syncbn_running_statistics": True}
