@@ -297,6 +297,35 @@ def main():
         dist.all_gather(gathered, digest)
         replicas_identical = {"parameters": all(bool(torch.equal(g[:2], gathered[0][:2])) for g in gathered),
                               "syncbn_running_statistics": all(bool(torch.equal(g[2:], gathered[0][2:])) for g in gathered)}
+    # latency of the statistics all-reduce (193 doubles = one 96-channel message), back to back on one stream, through
+    # every transport this run has: what the 241 messages per step cost on the dependent chain
+    collective_us = None
+    if world > 1 or single_dp:
+        from lidog_amd import _lib as _L
+        from lidog_amd.comm import transport
+        tr = transport()
+        msg = torch.ones(193, dtype=torch.float64, device="cuda")
+        ways = {}
+        if tr.peer:
+            ways["peer_one_shot"] = lambda: _L.call("lidog_peer_allreduce_f64", tr.peer, _L.ptr(msg), msg.numel())
+        if tr.comm_bn:
+            ways["rccl"] = lambda: _L.call("lidog_allreduce_f64", _L.ptr(msg), msg.numel(), tr.comm_bn)
+        ways["torch_distributed"] = lambda: dist.all_reduce(msg)
+        collective_us = {}
+        for name, fn in ways.items():
+            reps = 200 if (name != "torch_distributed" or dist.get_backend() == "nccl") else 5   # gloo stages through the host
+            for _ in range(3):
+                fn()
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                msg.fill_(1.0)
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            collective_us[name] = round(1e3 * e0.elapsed_time(e1) / reps, 2)
+        sync()
     eval_rate = None
     if world == 1:
         # secondary figure: forward-only validation path, is_train=False, same batches
@@ -333,6 +362,7 @@ def main():
             res["config"]["trunk_path"] = "executor" if getattr(step, "last_path", "") == "_TrunkFnBackward" else \
                 getattr(step, "last_path", "unknown")
             res["replicas_identical"] = replicas_identical   # parameters + running statistics equal on every rank
+            res["statistics_allreduce_us"] = collective_us    # per call, 193 doubles, incl. a fill kernel (rank 0's clock)
         if eval_rate is not None:
             res["forward_only_scans_per_s"] = eval_rate
         s = timer.summary()
