@@ -679,6 +679,8 @@ _BITMAP_MIN_ROWS = int(os.environ.get("LIDOG_MAP_BITMAP_MIN_ROWS", "40000"))
 
 # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X (LIDOG_WGRAD_BLOCKS: A/B runs)
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("LIDOG_WGRAD_BLOCKS", "2048"))
+# the >= 256 x 256 layers (few pairs, 256 KB partial slots): A/B switch
+_WGRAD_WIDE_BLOCKS = int(os.environ.get("LIDOG_WGRAD_WIDE_BLOCKS", str(_WGRAD_TARGET_BLOCKS)))
 
 
 def _wgrad_chunk(P, Cin, Cout):
@@ -692,6 +694,8 @@ def _wgrad_chunk(P, Cin, Cout):
     # measured on MI355X (scripts/sweep_wgrad.py): 8 workgroups per CU for the wide layers, 4 for the narrow ones
     # (their partial slots are cheap to compute and the final slot sum dominates)
     blocks = _WGRAD_TARGET_BLOCKS if Cin * Cout >= 128 * 128 else _WGRAD_TARGET_BLOCKS // 2
+    if Cin * Cout >= 256 * 256:
+        blocks = _WGRAD_WIDE_BLOCKS
     target = max(1, blocks // tiles)
     chunk = max(128, -(-P // target))
     max_items = max(1, (192 << 20) // (4 * Cin * Cout))             # at most ~192 MB of partial slots
