@@ -159,11 +159,66 @@ def cpu_baseline(config, steps_budget_s=20.0, threads=None):
                       f"{dt:.1f} s timed"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks as fresh children -- the driver's own
+    line, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py ...` -- BEFORE this process touches the GPU (a process that has initialised HIP must not be replaced or
+    forked), relay what they print (rank 0's JSON line) and exit with their code.  A watchdog ends a run that prints
+    nothing for LIDOG_BENCH_WATCHDOG_S seconds (default 1500): the children's process group is killed and the parent
+    exits non-zero, so a hung collective can never hang the caller."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.environ.get("LIDOG_BENCH_RANK_SCRIPT", os.path.abspath(__file__))] + sys.argv[1:]   # (script override: tests)
+    limit = float(os.environ.get("LIDOG_BENCH_WATCHDOG_S", "1500"))
+    env = dict(os.environ, LIDOG_BENCH_LAUNCHED_BY_PARENT="1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, start_new_session=True, text=True)
+    last = [time.time()]
+    timed_out = [False]
+
+    def watchdog():
+        while proc.poll() is None:
+            if time.time() - last[0] > limit:
+                timed_out[0] = True
+                try:
+                    os.killpg(proc.pid, signal.SIGTERM)
+                    time.sleep(10)
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                return
+            time.sleep(1.0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    for line in proc.stdout:
+        last[0] = time.time()
+        # rank 0's result goes to stdout, everything else (launcher banners, warnings) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        (sys.stdout if line.startswith("{") else sys.stderr).flush()
+    rc = proc.wait()
+    if timed_out[0]:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run printed nothing for {limit:.0f} s and was killed\n")
+        rc = rc or 124
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        # checked before any collective or GPU work: every rank sees the same mismatch and leaves with the same message
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; run "
+                 f"`python bench.py --gpus {args.gpus}` (it starts its ranks itself) or launch {args.gpus} ranks")
     # test hooks only: LIDOG_BENCH_ONE_GPU=1 runs every rank on cuda:0 over gloo so the multi-rank control flow
     # (SyncBN conversion, gradient buckets, barriers, max-over-ranks) can be exercised on a 1-GPU box
     one_gpu = os.environ.get("LIDOG_BENCH_ONE_GPU") == "1"
@@ -186,7 +241,6 @@ def main():
                     sk.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import lidog_amd
     import lidog_amd.me as ME

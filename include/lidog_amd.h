@@ -386,8 +386,18 @@ int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_doubles, vo
 int32_t lidog_peer_max_doubles(void *comm);
 int lidog_peer_set_spin_limit(void *comm, int64_t polls /* ~1-2 us each; 0 = default, several minutes */);
 int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void *stream);
-int32_t lidog_peer_status(void *comm);
+int32_t lidog_peer_status(void *comm);   /* 0 ok, 1 a sender's flag never arrived, 2 a sender was ahead (desynchronised) */
 int lidog_peer_comm_destroy(void *comm, int32_t close_peers);
+/* A communicator's calls must all be queued on one stream (the mailbox slots are reused in stream order): the first
+ * call binds it, a call on another stream is refused; lidog_peer_rebind_stream waits for the old stream and moves it. */
+int lidog_peer_rebind_stream(void *comm, void *stream);
+int64_t lidog_peer_calls(void *comm);    /* calls made so far (= the sequence number of the last one) */
+/* test hook of the failure path: the call with this (1-based) sequence number raises no flags on this rank, so every
+ * rank's wait for it runs into the limit, sets the error word and -- from then on -- waits for nothing */
+int lidog_peer_inject_skip_flag(void *comm, int64_t seq);
+/* frees a mailbox that never became part of a communicator (set-up failed half way) */
+int lidog_peer_mailbox_free(void *ptr);
+int lidog_peer_mailbox_close(void *peer_ptr);
 
 /* ------------------------------------------------------------------ host-side tables of a kernel map (csrc/hostprep.hip)
  * Pure host code.  k_off_host [K+1]: the rule book's offsets (lidog_kernel_map_pairs' k_off copied to the host).
@@ -467,6 +477,9 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
  * (lidog_sconv_reduce_rows_bwdstats); 2 = the ReLU masks of BatchNorm + residual + ReLU layers kept as bits
  * (lidog_bn_apply_bits).  mask >= 0 sets it; returns the previous mask.  Set it between passes, not between a forward
  * pass and its backward pass. */
+/* a stream restricted to the compute units whose bits are set (hipExtStreamCreateWithCUMask): lets the caller keep the
+ * weight-gradient stream of the backward pass off part of the chip (lidog_amd.me._WgradLane, LIDOG_LANE_CU_MASK) */
+int lidog_stream_create_cu_mask(const uint32_t *mask, int32_t words, void **stream_out);
 int32_t lidog_trunk_fusions(int32_t mask);
 /* Timing of the executor's gathered-GEMM launches for the roofline figure of bench.py: on != 0 brackets every such
  * launch with HIP events on its stream; _read waits for the recorded launches, returns (launches, total ms, algorithmic

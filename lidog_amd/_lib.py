@@ -97,8 +97,14 @@ SIGNATURES = {
     "lidog_peer_allreduce_f64": [_p, _p, _i64, _p],
     "lidog_peer_status": [_p],
     "lidog_peer_comm_destroy": [_p, _i32],
+    "lidog_peer_rebind_stream": [_p, _p],
+    "lidog_peer_calls": [_p],
+    "lidog_peer_inject_skip_flag": [_p, _i64],
+    "lidog_peer_mailbox_free": [_p],
+    "lidog_peer_mailbox_close": [_p],
     "lidog_tiles_host": [_p, _i32, _i32, _i32, _p, _i64],
     "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
+    "lidog_stream_create_cu_mask": [_p, _i32, ctypes.POINTER(ctypes.c_void_p)],
     "lidog_trunk_fusions": [_i32],
     "lidog_trunk_gemm_timing": [_i32],
     "lidog_trunk_gemm_timing_read": [_p],
@@ -110,7 +116,11 @@ _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "
              "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
              "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64, "lidog_bitmap_words": _i64,
              "lidog_bn_bwd_reduce_blocks": _i64, "lidog_relu_bits_words": _i64,
-             "lidog_peer_mailbox_bytes": _i64}
+             "lidog_peer_mailbox_bytes": _i64, "lidog_peer_calls": _i64}
+
+# lidog_abi_version() of the library these signatures were written against: a stale .so (or a header an external caller
+# compiled against long ago) would take mis-sized arguments without any diagnostic
+ABI_VERSION = 4
 
 _lib = None
 
@@ -125,6 +135,10 @@ def load():
         L = ctypes.CDLL(SO_PATH)
         L.lidog_last_error.restype = ctypes.c_char_p
         L.lidog_last_error.argtypes = []
+        have = L.lidog_abi_version()
+        if have != ABI_VERSION:
+            raise RuntimeError(f"{SO_PATH} is ABI version {have}, this package expects {ABI_VERSION}: rebuild it with "
+                               "`python -m lidog_amd.build --force`")
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args

@@ -3,7 +3,13 @@
 // nn.BatchNorm1d inside ME.MinkowskiBatchNorm (utils/models/minkunet_bev.py:60,406-408),
 // nn.BatchNorm2d of utils/models/conv2d.py:18,21; eps 1e-5, momentum 0.1, biased variance for
 // normalisation, unbiased for running_var.
+#include <stdlib.h>
+
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
+#include "stats_tail.h"
 
 // MODE 0: (x, x*x)            -> statistics
 // MODE 1: (dy', dy' * xhat)   -> backward reductions, dy' = dy * (relu_y > 0) when relu_y given
@@ -28,8 +34,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict__ x, const float4 *__restrict__ dy,
                                                        const float4 *__restrict__ ry, int64_t n, int C4,
                                                        const float *__restrict__ mean,
-                                                       const float *__restrict__ invstd,
-                                                       double *__restrict__ partial,
+                                                       const float *__restrict__ invstd, StatsTail tail,
                                                        const float *__restrict__ rw = nullptr,
                                                        const float *__restrict__ rb = nullptr,
                                                        const uint32_t *__restrict__ rbits = nullptr) {
@@ -94,19 +99,14 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
     for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
     __syncthreads();
     if (active && r == 0) {
-        const int C = C4 * 4;
         for (int rr = 1; rr < RB; ++rr)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
-        // one partial row per workgroup, summed in block order by k_partials_sum: no atomics (512 workgroups
-        // adding to the same 2C addresses cost ~25 us of serialised L2 atomics), bit-reproducible
-        double *dst = partial + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dst[c4 * 4 + j] = a[j];
-            dst[C + c4 * 4 + j] = a[4 + j];
-        }
     }
+    // one partial row per workgroup, added in a fixed order by the last workgroup to arrive (stats_tail.h): no atomics
+    // on the sums (512 workgroups adding to the same 2C addresses cost ~25 us of serialised L2 atomics),
+    // bit-reproducible, and no finishing launch behind this one
+    lidog_stats_tail(tail, active && r == 0, c4, a);
 }
 
 // sums[col] = sum over blocks (ascending, fixed tree) of partial[b][col] for the 2C columns (C first sums, C second
@@ -115,18 +115,7 @@ __global__ __launch_bounds__(256) void k_colreduce_nc4(const float4 *__restrict_
 //   count > 0   -> sums[2C] = count   (SyncBatchNorm all-reduces the row count together with the sums)
 //   fin.mean    -> mean / invstd / running statistics from (sum x, sum x^2) and count  (= k_bn_finalize)
 //   fin.db / dw -> float copies of (first sums, second sums)                            (= k_bn_param_grads)
-__device__ __forceinline__ void bn_finalize_channel(double sx, double sxx, double count, int c, const BnFinish &fin) {
-    double m = sx / count;
-    double var = sxx / count - m * m;
-    if (var < 0) var = 0;
-    fin.mean[c] = (float)m;
-    fin.invstd[c] = (float)(1.0 / sqrt(var + (double)fin.eps));
-    if (fin.running_mean) {
-        double unb = (count > 1) ? var * count / (count - 1) : var;
-        fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)m;
-        fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unb;
-    }
-}
+#define bn_finalize_channel lidog_bn_finalize_channel   // stats_tail.h
 
 __global__ __launch_bounds__(256) void k_sums_finish(const double *__restrict__ partial, int nb, int C,
                                                      double *__restrict__ sums, double count, BnFinish fin) {
@@ -240,6 +229,45 @@ __global__ __launch_bounds__(256) void k_colreduce_strided(const float *__restri
     }
 }
 
+// Ticket words of the in-kernel finish (stats_tail.h): one block of 1 + STATS_MAX_GROUPS words per stream, zeroed when it
+// is created and left zeroed by every launch that used it.  Launches that share a block are ordered by their stream.
+unsigned *lidog_stats_tickets(hipStream_t stream) {
+    static std::unordered_map<hipStream_t, unsigned *> blocks;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    auto it = blocks.find(stream);
+    if (it != blocks.end()) return it->second;
+    unsigned *p = nullptr;
+    const size_t bytes = sizeof(unsigned) * (1 + STATS_MAX_GROUPS + 63) / 64 * 64;
+    if (hipMalloc((void **)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+        lidog_set_error("stats tickets: cannot allocate %zu bytes of device memory", bytes);
+        return nullptr;
+    }
+    blocks[stream] = p;
+    return p;
+}
+
+int lidog_stats_tail_make(StatsTail *tail, double *partial, double *sums, double count, int C, BnFinish fin,
+                          hipStream_t st) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("LIDOG_STATS_TAIL");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    unsigned *tickets = nullptr;
+    if (on) {
+        tickets = lidog_stats_tickets(st);
+        if (!tickets) return 1;
+    }
+    *tail = StatsTail{partial, tickets, sums, count, C, fin};
+    return 0;
+}
+
+int lidog_stats_tail_finish(const StatsTail &tail, int nb, hipStream_t st) {
+    if (tail.tickets) return 0;
+    return lidog_launch_sums_finish(tail.partial, nb, tail.C, tail.sums, tail.count, tail.fin, st);
+}
+
 static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4 == 0 && C / 4 <= 256; }
 #define COLREDUCE_MAX_BLOCKS 512
 #define COLREDUCE_PLANE_CHUNKS 64   // chunks of an NCHW plane (one workgroup each)
@@ -284,9 +312,11 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
         int64_t nb = cdiv64(n, (int64_t)RB * 4 * COLREDUCE_ROUNDS);
         if (nb > COLREDUCE_MAX_BLOCKS) nb = COLREDUCE_MAX_BLOCKS;
         if (MODE == 1) nb = lidog_bn_bwd_reduce_blocks(n, C);
+        StatsTail tail;
+        if (lidog_stats_tail_make(&tail, ws, sums, count, C, fin, st)) return 1;
         k_colreduce_nc4<MODE><<<(unsigned)nb, 256, 0, st>>>((const float4 *)x, (const float4 *)dy, (const float4 *)ry,
-                                                            n, C4, mean, invstd, ws, rw, rb, rbits);
-        lidog_launch_sums_finish(ws, (int)nb, C, sums, count, fin, st);
+                                                            n, C4, mean, invstd, tail, rw, rb, rbits);
+        lidog_stats_tail_finish(tail, (int)nb, st);
     } else {
         LIDOG_REQUIRE(rw == nullptr && rbits == nullptr,
                       "bn reduce: ReLU masks from x or from a bit mask only for [rows, C] with C %% 4 == 0");
@@ -314,7 +344,7 @@ static int launch_colreduce(const float *x, const float *dy, const float *ry, in
 // doubles of workspace: [rows, C] with C % 4 == 0: the table of per-workgroup partials; NCHW (hw > 1): PER IMAGE
 // (multiply by the number of images); 0 otherwise
 extern "C" int64_t lidog_bn_reduce_ws(int32_t C, int64_t hw) {
-    if (colreduce_uses_partials(C, hw)) return (int64_t)COLREDUCE_BWD_MAX_BLOCKS * 2 * C;
+    if (colreduce_uses_partials(C, hw)) return (int64_t)(COLREDUCE_BWD_MAX_BLOCKS + STATS_MAX_GROUPS) * 2 * C;
     return hw > 1 ? (int64_t)COLREDUCE_PLANE_CHUNKS * 2 * C : 0;
 }
 

@@ -115,6 +115,12 @@ extern "C" int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *str
 #define PEER_MAX_RANKS 16
 #define PEER_SPIN_LIMIT_DEFAULT (1u << 27)   // x ~1-2 us of sleep + system-scope load: several minutes (a rank may be
                                             // busy writing a checkpoint while the others wait for its message)
+// error word of a communicator: 0 ok, 1 = a sender's flag did not arrive within the wait limit, 2 = a sender is AHEAD
+// of this rank (its flag carries a later sequence number: the ranks no longer make the same calls).  Once it is set
+// no later call waits for anything (the step runs on, on invalid sums, at full speed; Transport.check() raises on
+// every rank at the next boundary): a dead or desynchronised peer costs ONE wait limit, not one per call.
+#define PEER_ERR_TIMEOUT 1
+#define PEER_ERR_DESYNC 2
 
 struct PeerComm {
     int rank, nranks, max_doubles, stride;
@@ -122,7 +128,10 @@ struct PeerComm {
     uint64_t seq;
     double *local;
     double *peers[PEER_MAX_RANKS];
-    int32_t *err_dev;    // 0 ok, 1 = timed out waiting for a sender
+    int32_t *err_dev;
+    hipStream_t stream;   // the stream of the first call; every later call must use it (slot reuse relies on stream order)
+    bool stream_set;
+    int skip_flag_at;     // fault injection (tests): the call with this sequence number raises no flags; 0 = never
 };
 
 struct PeerArgs {
@@ -132,30 +141,52 @@ struct PeerArgs {
     unsigned spin_limit;
     uint64_t seq;
     int32_t *err;
+    int skip_flag;
 };
+
+static inline int peer_stride(int max_doubles) {
+    // data (rounded up to whole 16-byte granules) + the flag in the last double, whole 128-byte lines per sender
+    return (int)(((int64_t)max_doubles + 2 + 15) / 16 * 16);
+}
+
+typedef double lidog_f64x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_peer_allreduce(PeerArgs a, double *__restrict__ buf, int n) {
     const int slot = (int)(a.seq & 1);
     const int tid = threadIdx.x;
-    // 1. push my vector into every rank's mailbox (my own included: the sum below reads all N the same way)
-    for (int idx = tid; idx < n * a.nranks; idx += 256) {
-        const int p = idx / n, i = idx - p * n;
+    const int n2 = (n + 1) / 2;     // 16-byte granules per message (an odd message carries one pad double)
+    const bool dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    // 1. push my vector into every rank's mailbox (my own included: the sum below reads all N the same way), one 16-byte
+    // store per granule: a posted write over the sender's direct xGMI link (the mailboxes are fine-grained memory:
+    // stores go through to the owner's memory).  513 doubles to 8 ranks = 2 056 stores (was 4 104 scalar ones).
+    for (int idx = tid; idx < n2 * a.nranks; idx += 256) {
+        const int p = idx / n2, i = idx - p * n2;
         double *dst = a.peers[p] + ((size_t)slot * a.nranks + a.rank) * a.stride;
-        __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        lidog_f64x2 v;
+        v.x = buf[2 * i];
+        v.y = (2 * i + 1 < n) ? buf[2 * i + 1] : 0.0;
+        *reinterpret_cast<lidog_f64x2 *>(dst + 2 * i) = v;
     }
     __threadfence_system();     // my stores are visible system-wide before any of my flags is
     __syncthreads();
     if (tid < a.nranks) {
         uint64_t *flag = reinterpret_cast<uint64_t *>(a.peers[tid] + ((size_t)slot * a.nranks + a.rank) * a.stride +
                                                       (a.stride - 1));
-        __hip_atomic_store(flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!a.skip_flag) __hip_atomic_store(flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // 2. wait for sender `tid` in MY mailbox
         const uint64_t *mine = reinterpret_cast<const uint64_t *>(
             a.local + ((size_t)slot * a.nranks + tid) * a.stride + (a.stride - 1));
         unsigned spins = 0;
-        while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+        for (;;) {
+            const uint64_t f = __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (f == a.seq) break;
+            if (f > a.seq) {    // the sender has moved on: this slot's data is gone
+                __hip_atomic_store(a.err, PEER_ERR_DESYNC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            if (dead) break;    // an earlier call failed: nothing waits any more
             if (++spins > a.spin_limit) {
-                *a.err = 1;
+                __hip_atomic_store(a.err, PEER_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -164,13 +195,16 @@ __global__ __launch_bounds__(256) void k_peer_allreduce(PeerArgs a, double *__re
     __syncthreads();
     __threadfence_system();
     // 3. the sum, in rank order
-    for (int i = tid; i < n; i += 256) {
-        double s = 0.0;
+    for (int i = tid; i < n2; i += 256) {
+        double s0 = 0.0, s1 = 0.0;
         for (int r = 0; r < a.nranks; ++r) {
             const double *src = a.local + ((size_t)slot * a.nranks + r) * a.stride;
-            s += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const lidog_f64x2 v = *reinterpret_cast<const lidog_f64x2 *>(src + 2 * i);
+            s0 += v.x;
+            s1 += v.y;
         }
-        buf[i] = s;
+        buf[2 * i] = s0;
+        if (2 * i + 1 < n) buf[2 * i + 1] = s1;
     }
 }
 
@@ -178,8 +212,7 @@ extern "C" int32_t lidog_peer_handle_bytes(void) { return (int32_t)sizeof(hipIpc
 
 extern "C" int64_t lidog_peer_mailbox_bytes(int32_t nranks, int32_t max_doubles) {
     if (nranks < 1 || nranks > PEER_MAX_RANKS || max_doubles < 1) return -1;
-    const int64_t stride = ((int64_t)max_doubles + 1 + 15) / 16 * 16;     // data + flag, whole 128-byte lines per sender
-    return 2 * (int64_t)nranks * stride * 8;
+    return 2 * (int64_t)nranks * peer_stride(max_doubles) * 8;
 }
 
 // fine-grained (uncached, coherent across agents) device memory for a mailbox, zeroed; handle_out: its hipIpc handle
@@ -223,8 +256,11 @@ extern "C" int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_
     c->rank = rank;
     c->nranks = nranks;
     c->max_doubles = max_doubles;
-    c->stride = (int)(((int64_t)max_doubles + 1 + 15) / 16 * 16);
+    c->stride = peer_stride(max_doubles);
     c->seq = 0;
+    c->stream = nullptr;
+    c->stream_set = false;
+    c->skip_flag_at = 0;
     c->spin_limit = PEER_SPIN_LIMIT_DEFAULT;
     c->local = (double *)local;
     for (int r = 0; r < nranks; ++r) c->peers[r] = (double *)peer_ptrs[r];
@@ -240,18 +276,27 @@ extern "C" int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_
 
 extern "C" int32_t lidog_peer_max_doubles(void *comm) { return comm ? ((PeerComm *)comm)->max_doubles : 0; }
 
-// polls a waiting rank makes before it gives up on a sender (each ~1-2 us); 0 restores the default (about a minute)
+// polls a waiting rank makes before it gives up on a sender (each ~1-2 us); 0 restores the default (several minutes)
 extern "C" int lidog_peer_set_spin_limit(void *comm, int64_t polls) {
     LIDOG_REQUIRE(comm && polls >= 0 && polls < ((int64_t)1 << 32), "peer_set_spin_limit: bad arguments");
     ((PeerComm *)comm)->spin_limit = polls ? (unsigned)polls : PEER_SPIN_LIMIT_DEFAULT;
     return 0;
 }
 
-// sum over the ranks of buf[0 .. n) in place, identical bits on every rank; every rank calls it in the same order
+// sum over the ranks of buf[0 .. n) in place, identical bits on every rank; every rank calls it in the same order, and
+// always on the same stream: the two mailbox slots alternate with the call number, and call k + 2 may only overwrite a
+// slot after call k has been read -- which stream order guarantees and two streams would not
 extern "C" int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void *stream) {
     PeerComm *c = (PeerComm *)comm;
     LIDOG_REQUIRE(c && buf && n >= 1 && n <= c->max_doubles, "peer_allreduce_f64: %lld doubles, the mailbox takes %d",
                   (long long)n, c ? c->max_doubles : 0);
+    if (!c->stream_set) {
+        c->stream = (hipStream_t)stream;
+        c->stream_set = true;
+    }
+    LIDOG_REQUIRE(c->stream == (hipStream_t)stream,
+                  "peer_allreduce_f64: called on another stream than the first call of this communicator (the mailbox "
+                  "slots are reused in stream order; lidog_peer_rebind_stream after a synchronisation moves it)");
     PeerArgs a;
     for (int r = 0; r < c->nranks; ++r) a.peers[r] = c->peers[r];
     a.local = c->local;
@@ -261,18 +306,51 @@ extern "C" int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void
     a.seq = ++c->seq;
     a.spin_limit = c->spin_limit;
     a.err = c->err_dev;
+    a.skip_flag = (c->skip_flag_at != 0 && (uint64_t)c->skip_flag_at == a.seq) ? 1 : 0;
     k_peer_allreduce<<<1, 256, 0, (hipStream_t)stream>>>(a, buf, (int)n);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
 
-// 0 = every wait so far was satisfied, 1 = a sender's flag did not arrive in time (synchronises with the device)
+// The communicator follows the caller to another stream: waits for everything queued on the old one first.
+extern "C" int lidog_peer_rebind_stream(void *comm, void *stream) {
+    PeerComm *c = (PeerComm *)comm;
+    LIDOG_REQUIRE(c != nullptr, "peer_rebind_stream: null communicator");
+    if (c->stream_set && c->stream != (hipStream_t)stream) LIDOG_CHECK_HIP(hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t)stream;
+    c->stream_set = true;
+    return 0;
+}
+
+// fault injection for the tests of the failure path: the call with sequence number `seq` (1-based) raises no flags
+extern "C" int lidog_peer_inject_skip_flag(void *comm, int64_t seq) {
+    PeerComm *c = (PeerComm *)comm;
+    LIDOG_REQUIRE(c != nullptr && seq >= 0, "peer_inject_skip_flag: bad arguments");
+    c->skip_flag_at = (int)seq;
+    return 0;
+}
+
+// calls made on this communicator so far
+extern "C" int64_t lidog_peer_calls(void *comm) { return comm ? (int64_t)((PeerComm *)comm)->seq : -1; }
+
+// 0 = every wait so far was satisfied, 1 = a sender's flag did not arrive in time, 2 = a sender was ahead of this rank
+// (synchronises with the device)
 extern "C" int32_t lidog_peer_status(void *comm) {
     PeerComm *c = (PeerComm *)comm;
     if (!c) return -1;
     int32_t e = -1;
     if (hipMemcpy(&e, c->err_dev, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return e;
+}
+
+extern "C" int lidog_peer_mailbox_free(void *ptr) {
+    if (ptr) LIDOG_CHECK_HIP(hipFree(ptr));
+    return 0;
+}
+
+extern "C" int lidog_peer_mailbox_close(void *peer_ptr) {
+    if (peer_ptr) LIDOG_CHECK_HIP(hipIpcCloseMemHandle(peer_ptr));
+    return 0;
 }
 
 extern "C" int lidog_peer_comm_destroy(void *comm, int32_t close_peers) {

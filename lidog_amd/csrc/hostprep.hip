@@ -70,12 +70,7 @@ extern "C" int64_t lidog_tiles_host(const int64_t *k_off_host, int32_t K, int32_
             rows[t] = (int32_t)(left < tile_rows ? left : tile_rows);
         }
     std::vector<int64_t> order;
-#ifdef HOSTPREP_EXP_PLAIN_TILE_ORDER   // experiment: tiles offset by offset
-    order.resize(total);
-    std::iota(order.begin(), order.end(), (int64_t)0);
-#else
     order_by_position(nt, total, order);
-#endif
     for (int64_t i = 0; i < total; ++i) {
         out[i] = tk[order[i]];
         out[total + i] = row0[order[i]];

@@ -3,6 +3,7 @@
 // weight gradient by split reduction over pairs.  CPU restatement: oracle/me_oracle.c
 // (orc_conv_fwd / orc_conv_bwd_data / orc_conv_bwd_weight).
 #include "common.h"
+#include "stats_tail.h"
 #include "sconv_mfma.h"
 
 // 1 = exact-f32 MFMA cores (default), 0 = vector-FMA cores; identical results, see sconv_mfma.hip
@@ -406,7 +407,7 @@ extern "C" int lidog_sconv_reduce(const float *T, const int32_t *pos, int64_t n,
 __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__restrict__ T,
                                                              const int32_t *__restrict__ pos, int64_t n, int K, int C4,
                                                              const float4 *__restrict__ bias, float4 *__restrict__ out,
-                                                             double *__restrict__ partial) {
+                                                             StatsTail tail) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
     const int tid = threadIdx.x;
@@ -430,17 +431,11 @@ __global__ __launch_bounds__(256) void k_sconv_reduce4_stats(const float4 *__res
     for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
     __syncthreads();
     if (active && r == 0) {
-        const int C = C4 * 4;
         for (int rr = 1; rr < RB; ++rr)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
-        double *dst = partial + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dst[c4 * 4 + j] = a[j];
-            dst[C + c4 * 4 + j] = a[4 + j];
-        }
     }
+    lidog_stats_tail(tail, active && r == 0, c4, a);   // partial row + in-kernel finish by the last workgroup
 }
 
 // ---- the same reductions over per-row lists (lidog_kernel_map_rows): out row o = sum of T[row_list[p]] for
@@ -509,11 +504,7 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4(const float4 *__rest
                                                             const float4 *__restrict__ bias,
                                                             const float4 *__restrict__ addend,
                                                             float4 *__restrict__ out) {
-#ifdef RED_EXP_REVERSE   // experiment: last rows first (their product rows were written last: still in the Infinity Cache?)
-    int64_t idx = (int64_t)(gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x;
-#else
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-#endif
     if (idx >= n * C4) return;
     int64_t o = idx / C4;
     int c4 = (int)(idx % C4);
@@ -533,8 +524,7 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *
                                                                   const int32_t *__restrict__ row_ptr,
                                                                   const int32_t *__restrict__ row_list, int64_t n,
                                                                   int C4, const float4 *__restrict__ bias,
-                                                                  float4 *__restrict__ out,
-                                                                  double *__restrict__ partial) {
+                                                                  float4 *__restrict__ out, StatsTail tail) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
     const int tid = threadIdx.x;
@@ -569,17 +559,11 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_stats(const float4 *
     for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
     __syncthreads();
     if (active && r == 0) {
-        const int C = C4 * 4;
         for (int rr = 1; rr < RB; ++rr)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
-        double *dst = partial + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dst[c4 * 4 + j] = a[j];
-            dst[C + c4 * 4 + j] = a[4 + j];
-        }
     }
+    lidog_stats_tail(tail, active && r == 0, c4, a);   // partial row + in-kernel finish by the last workgroup
 }
 
 // Data-gradient reduction whose epilogue is the BatchNorm-backward reduction of the layer that PRODUCED the rows it
@@ -593,7 +577,7 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
     const float4 *__restrict__ T, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ row_list, int64_t n,
     int C4, const float4 *__restrict__ addend, float4 *__restrict__ out, const float4 *__restrict__ pre,
     const float4 *__restrict__ relu_y, const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ rw, const float *__restrict__ rb, double *__restrict__ partial,
+    const float *__restrict__ rw, const float *__restrict__ rb, StatsTail tail,
     const uint32_t *__restrict__ rbits) {
     __shared__ double red[256 * 8];
     const int RB = 256 / C4;
@@ -656,17 +640,11 @@ __global__ __launch_bounds__(256) void k_sconv_reduce_rows4_bwdstats(
     for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[j];
     __syncthreads();
     if (active && r == 0) {
-        const int C = C4 * 4;
         for (int rr = 1; rr < RB; ++rr)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += red[(rr * C4 + c4) * 8 + j];
-        double *dst = partial + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dst[c4 * 4 + j] = a[j];
-            dst[C + c4 * 4 + j] = a[4 + j];
-        }
     }
+    lidog_stats_tail(tail, active && r == 0, c4, a);   // partial row + in-kernel finish by the last workgroup
 }
 
 extern "C" int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *row_ptr, const int32_t *row_list,
@@ -684,11 +662,13 @@ extern "C" int lidog_sconv_reduce_rows_bwdstats(const float *T, const int32_t *r
     if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * C + 1), st) == hipSuccess ? 0 : 1;
     const int C4 = C / 4;
     const int64_t nb = lidog_bn_bwd_reduce_blocks(n, C);   // the grid of lidog_bn_bwd_reduce: same partials
+    BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
+    StatsTail tail;
+    if (lidog_stats_tail_make(&tail, partial_ws, sums, count, C, fin, st)) return 1;
     k_sconv_reduce_rows4_bwdstats<<<(unsigned)nb, 256, 0, st>>>(
         (const float4 *)T, row_ptr, row_list, n, C4, (const float4 *)addend, (float4 *)out, (const float4 *)pre,
-        (const float4 *)relu_y, mean, invstd, relu_w, relu_b, partial_ws, relu_bits);
-    BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
-    lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
+        (const float4 *)relu_y, mean, invstd, relu_w, relu_b, tail, relu_bits);
+    lidog_stats_tail_finish(tail, (int)nb, st);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -772,10 +752,12 @@ extern "C" int lidog_sconv_reduce_rows_stats(const float *T, const int32_t *row_
 #endif
     int64_t nb = cdiv64(n, (int64_t)RB * RED_STATS_ROWS);
     if (nb > lidog_stats_max_blocks()) nb = lidog_stats_max_blocks();
-    k_sconv_reduce_rows4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, row_ptr, row_list, n, C4,
-                                                             (const float4 *)bias, (float4 *)out, partial_ws);
     BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
-    lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
+    StatsTail tail;
+    if (lidog_stats_tail_make(&tail, partial_ws, sums, count, C, fin, st)) return 1;
+    k_sconv_reduce_rows4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, row_ptr, row_list, n, C4,
+                                                             (const float4 *)bias, (float4 *)out, tail);
+    lidog_stats_tail_finish(tail, (int)nb, st);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -859,7 +841,7 @@ extern "C" int lidog_sconv_cin1(const float *x, const int32_t *nbr, const float 
 extern "C" int64_t lidog_sconv_reduce_stats_ws(int64_t n, int32_t C) {
     // doubles of workspace needed by lidog_sconv_reduce_stats
     (void)n;
-    return (int64_t)2048 * 2 * C;
+    return (int64_t)(2048 + STATS_MAX_GROUPS) * 2 * C;
 }
 
 extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int64_t n, int32_t K, int32_t C,
@@ -874,10 +856,12 @@ extern "C" int lidog_sconv_reduce_stats(const float *T, const int32_t *pos, int6
     int C4 = C / 4, RB = 256 / C4;
     int64_t nb = cdiv64(n, (int64_t)RB * 4);
     if (nb > 2048) nb = 2048;
-    k_sconv_reduce4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, pos, n, K, C4, (const float4 *)bias,
-                                                        (float4 *)out, partial_ws);
     BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
-    lidog_launch_sums_finish(partial_ws, (int)nb, C, sums, count, fin, st);
+    StatsTail tail;
+    if (lidog_stats_tail_make(&tail, partial_ws, sums, count, C, fin, st)) return 1;
+    k_sconv_reduce4_stats<<<(unsigned)nb, 256, 0, st>>>((const float4 *)T, pos, n, K, C4, (const float4 *)bias,
+                                                        (float4 *)out, tail);
+    lidog_stats_tail_finish(tail, (int)nb, st);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

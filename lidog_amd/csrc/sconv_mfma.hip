@@ -6,6 +6,8 @@
 //
 // MFMA 32x32x2 lane maps: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 // D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5) for accumulator register e.
+#include <stdlib.h>
+
 #include "common.h"
 #include "sconv_mfma.h"
 
@@ -60,11 +62,10 @@ __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
 
 // ------------------------------------------------------------------ gathered GEMM
 // Tile 128 pair-rows x 32*NT columns; wave w owns rows [32w, 32w+32) and all NT column tiles.
-#ifndef MG_MIN_WAVES
-#define MG_MIN_WAVES 1
-#endif
-template <int NT>
-__global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const float *__restrict__ A,
+// MINW: waves per SIMD the register allocation must leave room for (1 = whatever the kernel likes: 140-144 registers,
+// three workgroups per CU; 4 = at most 128 registers, four workgroups per CU -- spill-free for the 96-column case only)
+template <int NT, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__restrict__ A,
                                                          const int32_t *__restrict__ gather,
                                                          const float *__restrict__ B,
                                                          const float *__restrict__ bias,
@@ -174,10 +175,7 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
         __syncthreads();
         // unconditional prefetch (the last iteration re-reads its own chunk): a branch around the staging
         // registers sends them through scratch memory
-#ifndef MG_EXP_NOLOAD    // experiment: no global loads inside the loop
         load_chunk(kb + MG_BK < Cin ? kb + MG_BK : kb);
-#endif
-#ifndef MG_EXP_NOMFMA    // experiment: data movement only
         const float *arow = &As[(wave * 32 + li) * MG_SA + kh];
         // MFMA column tile t of this wave = columns {li * NT + t}: the NT B operands of one k step are adjacent
         // in the row-major LDS image (one wide LDS read), and the NT results of a lane are adjacent in T (one
@@ -215,7 +213,6 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
                 a1 = an1;
             }
         }
-#endif
     }
 
     // Epilogue.  Nothing may be pending in vmcnt here except the stores themselves: with a load outstanding (the bias
@@ -239,9 +236,6 @@ __global__ __launch_bounds__(256, MG_MIN_WAVES) void k_sconv_gemm_mfma(const flo
     for (int e = 0; e < 16; ++e) {
         int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         int dst = scatter ? s_dst[r] : (r < rows ? row0 + r : -1);
-#ifdef MG_EXP_NOSTORE    // experiment: no product-row stores (kept live by a never-true condition)
-        if (acc[0][e] != 1.2345e30f) dst = -1;
-#endif
         if (dst >= 0) {
             float *out = T + (size_t)dst * Cout + col0 + li * NT;
             float v[NT];
@@ -257,14 +251,22 @@ int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B
                            int Cin, int Cout, float *T, const int32_t *scatter, hipStream_t st) {
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)n_tiles, (unsigned)(Cout / (32 * nt)));
-#define LAUNCH(NT_)                                                                                               \
-    k_sconv_gemm_mfma<NT_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, \
-                                                 scatter)
+#define LAUNCH(NT_, MW_)                                                                                          \
+    k_sconv_gemm_mfma<NT_, MW_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, \
+                                                      scatter)
+    static int waves3 = -1;   // LIDOG_GEMM3_WAVES=4: the 96-column kernel at four workgroups per CU (A/B switch)
+    if (waves3 < 0) {
+        const char *e = getenv("LIDOG_GEMM3_WAVES");
+        waves3 = (e && atoi(e) == 4) ? 4 : 1;
+    }
     switch (nt) {
-        case 4: LAUNCH(4); break;
-        case 3: LAUNCH(3); break;
-        case 2: LAUNCH(2); break;
-        default: LAUNCH(1);
+        case 4: LAUNCH(4, 1); break;
+        case 3:
+            if (waves3 == 4) LAUNCH(3, 4);
+            else LAUNCH(3, 1);
+            break;
+        case 2: LAUNCH(2, 1); break;
+        default: LAUNCH(1, 1);
     }
 #undef LAUNCH
     return 0;

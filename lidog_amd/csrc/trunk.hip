@@ -81,6 +81,11 @@ struct Dp {
     const int64_t *d;
     bool sync_bn() const { return d && d[DP_SYNC_BN] != 0; }
     bool buckets() const { return d && d[DP_N_BUCKETS] > 0 && d[DP_PENDING] && d[DP_PARAM_BUCKET]; }
+    // the peer communicator's calls are bound to one stream (csrc/comm.hip): follow this pass's launch stream
+    int bind(void *st) const {
+        if (d && d[DP_PEER]) return lidog_peer_rebind_stream(P<void>(d[DP_PEER]), st);
+        return 0;
+    }
     int check() const {
         if (!d) return 0;
         LIDOG_REQUIRE(!d[DP_SYNC_BN] || d[DP_COMM_BN] || d[DP_CALLBACK] || d[DP_PEER],
@@ -112,22 +117,6 @@ struct Dp {
             if (_rc) return _rc;  \
         }                         \
     } while (0)
-
-#ifdef TRUNK_EXP_SKIP   // timing experiments (results are garbage): LIDOG_TRUNK_SKIP = bit mask of kernel families left out
-#include <stdlib.h>
-static int exp_skip() {
-    static int v = -1;
-    if (v < 0) v = getenv("LIDOG_TRUNK_SKIP") ? atoi(getenv("LIDOG_TRUNK_SKIP")) : 0;
-    return v;
-}
-#define TRYX(bit, expr)                      \
-    do {                                     \
-        if (!(exp_skip() & (bit))) TRY(expr); \
-    } while (0)
-static int g_gemm_bit = 1;
-#else
-#define TRYX(bit, expr) TRY(expr)
-#endif
 
 // events for forking the lane stream behind the main stream (one per convolution) and joining it again; one pool per
 // process (one process drives one GPU), grown under a lock: backward passes run on autograd's device threads
@@ -240,9 +229,6 @@ hipEvent_t timing_event() {
 int gemm(const Ctx &ctx, const int64_t *m, const float *A, int64_t n_src, const int32_t *gather, const float *B,
          const float *bias, int Cin, int Cout, float *out, const int32_t *scatter, void *st) {
     if (ctx.dry) return 0;
-#ifdef TRUNK_EXP_SKIP
-    if (exp_skip() & g_gemm_bit) return 0;   // 1 = forward GEMMs, 32 = data-gradient GEMMs
-#endif
     GemmRec rec{nullptr, nullptr, 0, 0};
     if (g_timing) {
         rec.e0 = timing_event();
@@ -287,9 +273,8 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                       (long long)want[1], (long long)arena_bytes, (long long)scratch_bytes);
     }
     Bump ar{(char *)arena, 0, arena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry};
-#ifdef TRUNK_EXP_SKIP
-    g_gemm_bit = 1;
-#endif
+    if (!ctx.dry && dp.sync_bn())
+        if (int rc = dp.bind(stream)) return rc;
     int64_t *buf_off = rec + (int64_t)n_ops * REC_COLS;
     // activation buffers: external ones are the caller's tensors, the others live in the arena
     std::vector<float *> bp(n_bufs, nullptr);
@@ -364,7 +349,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             const int32_t *rp = P<const int32_t>(m[TM_RP_OUT]), *rl = P<const int32_t>(m[TM_RL_OUT]);
             if (bn) {
                 double *ws = (double *)sc.take(lidog_sconv_reduce_stats_ws(n, Cout) * 8);
-                TRYX(2, lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, f_eps, f_mom,
+                TRY(lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, f_eps, f_mom,
                                                       f_mean, f_invstd, f_rm, f_rv, stream));
                 stats_done = true;
             } else {
@@ -383,7 +368,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         if (bn && !stats_done) {
             int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
             double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-            TRYX(4, lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
+            TRY(lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
         }
         pd = Pending{op, c, pre, mean, invstd, y, bits, sums, n, Cout, eps, mom};
         return 0;
@@ -394,7 +379,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             TRY(lidog_bn_finalize(pd.sums, -1.0, pd.Cout, pd.eps, pd.mom, pd.mean, pd.invstd, P<float>(c[TC_BNRM]),
                                   P<float>(c[TC_BNRV]), stream));
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
-        TRYX(4, lidog_bn_apply_bits(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
+        TRY(lidog_bn_apply_bits(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
                                     P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, stream));
         return 0;
     };
@@ -465,9 +450,8 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     Bump ga{(char *)garena, 0, garena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry},
         ls{(char *)lane_scratch, 0, lane_bytes, 0, ctx.dry};
     hipStream_t main_st = (hipStream_t)stream, lane_st = (hipStream_t)lane;
-#ifdef TRUNK_EXP_SKIP
-    g_gemm_bit = 32;
-#endif
+    if (!ctx.dry && dp.sync_bn())
+        if (int rc = dp.bind(stream)) return rc;
     hipEvent_t *events = nullptr;
     const bool sync = dp.sync_bn(), buckets = dp.buckets() && !ctx.dry;
     const int n_buckets = buckets ? (int)dp.d[DP_N_BUCKETS] : 0;
@@ -583,7 +567,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 sums = (double *)sc.take((2 * Cout + 1) * 8);
                 int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
                 double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-                TRYX(8, lidog_bn_bwd_reduce_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, sums, ws, (double)n,
+                TRY(lidog_bn_bwd_reduce_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, sums, ws, (double)n,
                                                  P<float>(c[TC_GBNW]), P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr,
                                                  mask_from_x ? bnb : nullptr, stream));
             }
@@ -591,7 +575,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
             // SyncBatchNorm: (sum dy', sum dy' xhat, rows) summed over the ranks; the apply kernel reads the global count
             if (sync) TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
-            TRYX(16, lidog_bn_bwd_apply_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, bnw, sums,
+            TRY(lidog_bn_bwd_apply_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, bnw, sums,
                                              sync ? -1.0 : (double)n, dx, dres, nullptr, nullptr,
                                              mask_from_x ? bnb : nullptr, stream));
             if (has_res)
@@ -631,7 +615,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             } else {
                 partial = (float *)sc.take(pbytes);
             }
-            TRYX(128, lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
+            TRY(lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
                                   P<const int32_t>(c[TC_ITEMOFF]), K, Cin, Cout, partial, P<float>(c[TC_GW]), st));
             return 0;
         };
@@ -683,7 +667,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                     const float *p_y = (p_relu && !p_from_x && !pr[REC_BITS]) ? bp[in_b] : nullptr;
                     double *sums = (double *)ga.take((2 * Cin + 1) * 8);   // lives until the producer's turn
                     double *ws = (double *)sc.take(lidog_bn_reduce_ws(Cin, 1) * 8);
-                    TRYX(64, lidog_sconv_reduce_rows_bwdstats(T, rp, rl, n_in, Cin, folds ? gp[in_b] : nullptr, gx, p_pre,
+                    TRY(lidog_sconv_reduce_rows_bwdstats(T, rp, rl, n_in, Cin, folds ? gp[in_b] : nullptr, gx, p_pre,
                                                               p_y, p_bits, p_mean, p_invstd,
                                                               p_from_x ? P<const float>(pc[TC_BNW]) : nullptr,
                                                               p_from_x ? P<const float>(pc[TC_BNB]) : nullptr, sums, ws,
@@ -694,11 +678,11 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                     gs[in_b] = 2;
                 } else if (folds) {
                     // the residual branch's gradient of the block input enters the sum in the reduction's epilogue
-                    TRYX(64, lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
+                    TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
                     gp[in_b] = gx;
                     gs[in_b] = 2;
                 } else {
-                    TRYX(64, lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, nullptr, gx, stream));
+                    TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, nullptr, gx, stream));
                     if (int rc = commit(in_b, gx)) return rc;
                 }
             }
@@ -729,6 +713,17 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     need[0] = ga.peak;
     need[1] = sc.peak;
     need[2] = ls.peak;
+    return 0;
+}
+
+// A stream whose kernels run on a subset of the compute units (the weight-gradient lane of the backward pass can be kept
+// off part of the chip so that the dependent chain on the launch stream always finds free CUs): mask bit i = CU i of the
+// runtime's enumeration, `words` 32-bit words.  The caller owns the stream (hipStreamDestroy through torch or at exit).
+extern "C" int lidog_stream_create_cu_mask(const uint32_t *mask, int32_t words, void **stream_out) {
+    LIDOG_REQUIRE(mask && words > 0 && stream_out, "stream_create_cu_mask: bad arguments");
+    hipStream_t st;
+    LIDOG_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+    *stream_out = (void *)st;
     return 0;
 }
 

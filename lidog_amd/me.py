@@ -13,6 +13,7 @@ Mirrors the surface of MinkowskiEngine 0.5.4 that LiDOG's models and pipelines u
 `import MinkowskiEngine as ME` resolves to it.  Everything runs on the GPU through the C ABI; there
 is no CPU path (tensors on the CPU raise).
 """
+import ctypes
 import math
 import os
 import sys
@@ -165,6 +166,37 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+def _masked_stream(device, spec):
+    """A stream restricted to part of the chip's 256 CUs (hipExtStreamCreateWithCUMask), or None for an empty spec.
+    spec: "first:N" (CUs 0 .. N-1 of the runtime's enumeration), "every:K" (every K-th CU), "skip:K" (all but every K-th)
+    or "hex:<mask>" (a 256-bit mask in hex, bit i = CU i).  An experiment hook of the backward pass's second stream
+    (LIDOG_LANE_CU_MASK): the default is an unrestricted stream."""
+    if not spec:
+        return None
+    kind, _, arg = spec.partition(":")
+    n_cus = 256
+    if kind == "first":
+        bits = [i < int(arg) for i in range(n_cus)]
+    elif kind == "every":
+        bits = [i % int(arg) == 0 for i in range(n_cus)]
+    elif kind == "skip":
+        bits = [i % int(arg) != 0 for i in range(n_cus)]
+    elif kind == "hex":
+        v = int(arg, 16)
+        bits = [(v >> i) & 1 == 1 for i in range(n_cus)]
+    else:
+        raise ValueError(f"CU mask {spec!r}: expected first:N, every:K, skip:K or hex:<mask>")
+    words = (ctypes.c_uint32 * (n_cus // 32))()
+    for i, b in enumerate(bits):
+        if b:
+            words[i // 32] |= 1 << (i % 32)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        if _lib.load().lidog_stream_create_cu_mask(words, n_cus // 32, ctypes.byref(out)) != 0:
+            raise RuntimeError(_lib.load().lidog_last_error().decode())
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 class _WgradLane:
     """Second stream of the backward pass.  A weight gradient depends only on tensors that exist when its
     convolution's backward starts and nothing in the backward chain depends on it, so it is queued on a side
@@ -192,7 +224,8 @@ class _WgradLane:
 
     def __init__(self, device):
         self.device = device
-        self.stream = torch.cuda.Stream(device=device, priority=_LANE_PRIORITY)
+        self.stream = _masked_stream(device, os.environ.get("LIDOG_LANE_CU_MASK", "")) or \
+            torch.cuda.Stream(device=device, priority=_LANE_PRIORITY)
         self.raw = self.stream.cuda_stream    # hipStream_t: kernels are launched on it without switching torch's stream
         self.keep = []
         self.pending = False
