@@ -309,6 +309,10 @@ int lidog_conv2d_fwd_sparse(const float *x, const float *w, const int32_t *act, 
                             int32_t W, int32_t Cout, float *y, float *ws, void *stream);
 int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const int32_t *act, int32_t B, int32_t Cin, int32_t H,
                               int32_t W, int32_t Cout, float *gx, float *ws, void *stream);
+/* FLOPs the three support-restricted kernels execute for the lists in `act` (out[0] forward, [1] data gradient,
+ * [2] weight gradient; padded stages included): measurement only, reads the list headers back (synchronises) */
+int lidog_conv2d_support_work(const int32_t *act, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                              double *out, void *stream);
 int64_t lidog_conv2d_wgrad_sparse_ws(int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout); /* floats of ws */
 int lidog_conv2d_wgrad_sparse(const float *x, const float *gy, const int32_t *act, int32_t B, int32_t Cin, int32_t H,
                               int32_t W, int32_t Cout, float *gw, float *ws, int64_t ws_floats, void *stream);
@@ -366,6 +370,7 @@ int32_t lidog_comm_unique_id_bytes(void);
 int lidog_comm_unique_id(void *id_out);
 int lidog_comm_init_rank(const void *id, int32_t nranks, int32_t rank, void **comm_out);
 int lidog_comm_destroy(void *comm);
+int32_t lidog_comm_count(void *comm);   /* ranks of the communicator as RCCL reports them (ncclCommCount); -1 on error */
 int lidog_allreduce_f32(float *buf, int64_t n, void *comm, void *stream);
 int lidog_allreduce_f64(double *buf, int64_t n, void *comm, void *stream);
 
@@ -398,6 +403,41 @@ int lidog_peer_inject_skip_flag(void *comm, int64_t seq);
 /* frees a mailbox that never became part of a communicator (set-up failed half way) */
 int lidog_peer_mailbox_free(void *ptr);
 int lidog_peer_mailbox_close(void *peer_ptr);
+
+/* ------------------------------------------------------------------ output-stationary 3^3 convolution (csrc/sconv_os.hip)
+ * MinkowskiConvolution(kernel_size=3, stride=1) without product rows: a workgroup owns 128 output rows, walks the
+ * kernel offsets in ascending order and adds each offset's product -- the same fmaf chain from zero as a row of
+ * lidog_sconv_gemm's T -- to the rows' running sum in the order lidog_sconv_reduce_rows adds them: identical results,
+ * no 4 P Cout bytes written and read back (utils/models/minkunet_bev.py:425-439, resnet_block.py:8-56).
+ * lidog_kernel_map_sorted: rows sorted by their neighbour mask (rarest offset = most significant bit) so that the rows
+ * of a tile share their offsets; perm [pad128(n)] (-1 behind the last row), wave_masks [pad128(n) / 32]: OR of the
+ * masks of every 32 sorted rows; tile_order [pad128(n) / 128]: the 128-row tiles in launch order (most work first).
+ * nbr / k_off: lidog_kernel_map(_bits) / lidog_kernel_map_pairs of the same map.
+ * lidog_sconv_os: out [n, Cout] = sum_k A[nbr[k][row]] W[k] (+ bias) (+ addend); reverse != 0 = the data gradient over
+ * the (symmetric) map: offsets from the top, weights W[K-1-k] (pass the transposed kernels, Cin / Cout swapped). */
+int64_t lidog_kernel_map_sorted_ws(int64_t n);
+int lidog_kernel_map_sorted(const int32_t *nbr, int64_t n, int32_t K, const int64_t *k_off, int32_t *perm,
+                            uint32_t *wave_masks, int32_t *tile_order, void *ws, int64_t ws_bytes, void *stream);
+int lidog_sconv_os(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                   const uint32_t *wave_masks, const int32_t *tile_order, const float *W, int32_t reverse,
+                   const float *bias, const float *addend, int32_t Cin, int32_t Cout, float *out, void *stream);
+/* the same with the reduction pass's statistics in the epilogue (one partial row per tile, finished in-kernel):
+ * lidog_sconv_os_stats = forward + BatchNorm statistics of the result (arguments as lidog_sconv_reduce_rows_stats);
+ * lidog_sconv_os_bwdstats = data gradient (+ addend) + the BatchNorm-backward sums of the layer whose output gradient it
+ * completes (arguments as lidog_sconv_reduce_rows_bwdstats; G [n, Cg], Wt [K][Cg][Cx], gx [n, Cx]).
+ * ws: lidog_sconv_os_stats_ws(n, C) doubles, C = width of the result. */
+int64_t lidog_sconv_os_stats_ws(int64_t n, int32_t C);
+int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                         const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias,
+                         int32_t Cin, int32_t Cout, float *out, double *sums, double *ws, double count, float eps,
+                         float momentum, float *mean, float *invstd, float *running_mean, float *running_var,
+                         void *stream);
+int lidog_sconv_os_bwdstats(const float *G, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                            const uint32_t *wave_masks, const int32_t *tile_order, const float *Wt, const float *addend,
+                            int32_t Cg, int32_t Cx, float *gx, const float *pre, const float *relu_y,
+                            const uint32_t *relu_bits, const float *mean, const float *invstd, const float *relu_w,
+                            const float *relu_b, double *sums, double *ws, double count, float *dw, float *db,
+                            void *stream);
 
 /* ------------------------------------------------------------------ host-side tables of a kernel map (csrc/hostprep.hip)
  * Pure host code.  k_off_host [K+1]: the rule book's offsets (lidog_kernel_map_pairs' k_off copied to the host).
@@ -486,6 +526,9 @@ int32_t lidog_trunk_fusions(int32_t mask);
  * FLOPs, algorithmic bytes: SURVEY.md 8(d)) in out[0..3] and forgets them.  One timing client per process. */
 int lidog_trunk_gemm_timing(int32_t on);
 int lidog_trunk_gemm_timing_read(double *out /*[4]*/);
+/* algorithmic bytes of the executor's MFMA weight-gradient and per-row reduction launches while the timing is on:
+ * out[0] launches / out[1] bytes (weight gradient), out[2] / out[3] (reduction); reading resets the counters */
+int lidog_trunk_work_read(double *out);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,13 @@ SIGNATURES = {
     "lidog_bn_bwd_reduce_blocks": [_i64, _i32],
     "lidog_stats_max_blocks": [],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
+    "lidog_kernel_map_sorted_ws": [_i64],
+    "lidog_kernel_map_sorted": [_p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p],
+    "lidog_sconv_os": [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
+    "lidog_sconv_os_stats_ws": [_i64, _i32],
+    "lidog_sconv_os_stats": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
+    "lidog_sconv_os_bwdstats": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                _d, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
     "lidog_set_sparse_core": [_i32],
@@ -87,6 +94,7 @@ SIGNATURES = {
     "lidog_comm_destroy": [_p],
     "lidog_allreduce_f32": [_p, _i64, _p, _p],
     "lidog_allreduce_f64": [_p, _i64, _p, _p],
+    "lidog_comm_count": [_p],
     "lidog_peer_handle_bytes": [],
     "lidog_peer_mailbox_bytes": [_i32, _i32],
     "lidog_peer_mailbox_alloc": [_i64, ctypes.POINTER(ctypes.c_void_p), _p],
@@ -104,10 +112,12 @@ SIGNATURES = {
     "lidog_peer_mailbox_close": [_p],
     "lidog_tiles_host": [_p, _i32, _i32, _i32, _p, _i64],
     "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
+    "lidog_conv2d_support_work": [_p, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_stream_create_cu_mask": [_p, _i32, ctypes.POINTER(ctypes.c_void_p)],
     "lidog_trunk_fusions": [_i32],
     "lidog_trunk_gemm_timing": [_i32],
     "lidog_trunk_gemm_timing_read": [_p],
+    "lidog_trunk_work_read": [_p],
     "lidog_trunk_forward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p, _p],
     "lidog_trunk_backward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
                              _i64, _p, _p, _i32, _i32, _p, _p, _p],
@@ -116,7 +126,8 @@ _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "
              "lidog_dice_ws": _i64, "lidog_colsum_ws": _i64, "lidog_conv2d_support_ws": _i64, "lidog_conv2d_wgrad_sparse_ws": _i64,
              "lidog_tiles_host": _i64, "lidog_wgrad_items_host": _i64, "lidog_bitmap_words": _i64,
              "lidog_bn_bwd_reduce_blocks": _i64, "lidog_relu_bits_words": _i64,
-             "lidog_peer_mailbox_bytes": _i64, "lidog_peer_calls": _i64}
+             "lidog_peer_mailbox_bytes": _i64, "lidog_peer_calls": _i64,
+             "lidog_kernel_map_sorted_ws": _i64, "lidog_sconv_os_stats_ws": _i64}
 
 # lidog_abi_version() of the library these signatures were written against: a stale .so (or a header an external caller
 # compiled against long ago) would take mis-sized arguments without any diagnostic

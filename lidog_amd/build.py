@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_C")
 SO = os.path.join(OUT_DIR, "liblidog_amd.so")
-SOURCES = ["coords.hip", "sconv.hip", "sconv_mfma.hip", "bn.hip", "bev.hip", "conv2d.hip", "conv2d_sparse.hip", "data.hip", "losses.hip", "optim.hip", "comm.hip", "trunk.hip", "hostprep.hip"]
+SOURCES = ["coords.hip", "sconv.hip", "sconv_mfma.hip", "sconv_os.hip", "bn.hip", "bev.hip", "conv2d.hip", "conv2d_sparse.hip", "data.hip", "losses.hip", "optim.hip", "comm.hip", "trunk.hip", "hostprep.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]

@@ -15,6 +15,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -35,6 +36,7 @@ int rccl_load() {
     SYM(GetUniqueId, "ncclGetUniqueId");
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommCount, "ncclCommCount");
     SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
@@ -73,6 +75,14 @@ extern "C" int lidog_comm_init_rank(const void *id, int32_t nranks, int32_t rank
     LIDOG_CHECK_NCCL(g_rccl.CommInitRank(&comm, nranks, uid, rank));
     *comm_out = (void *)comm;
     return 0;
+}
+
+// ranks of the communicator as RCCL itself reports them (bench.py prints it: evidence of how many GPUs really took part)
+extern "C" int32_t lidog_comm_count(void *comm) {
+    if (comm == nullptr || rccl_load()) return -1;
+    int n = -1;
+    if (g_rccl.CommCount((ncclComm_t)comm, &n) != ncclSuccess) return -1;
+    return n;
 }
 
 extern "C" int lidog_comm_destroy(void *comm) {

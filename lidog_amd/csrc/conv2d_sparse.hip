@@ -10,6 +10,8 @@
 //          written.
 // The activity comes from a `support` tensor [B,Cin,H,W] int32 (>= 0 where the cell is non-empty: the arg-max
 // source map of the pooling): one pass turns it into a bit per cell, a second one into per-tile channel lists.
+#include <vector>
+
 #include "conv2d.h"
 
 // ------------------------------------------------------------------ support -> row bitmasks -> tile lists
@@ -723,5 +725,42 @@ extern "C" int lidog_conv2d_wgrad_sparse(const float *x, const float *gy, const 
     k_sum_group_splits<<<(unsigned)cdiv64(slab, 256), 256, 0, st>>>(ws, slab, p.Nj, act + L.glists_off, L.fwd_tiles,
                                                                     gw);
     LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Matrix work the three support-restricted kernels EXECUTE for the lists in `act` (bench.py's `bev_mfma_frac`: executed
+// FLOPs, not the dense-equivalent figure): out[0] forward, out[1] data gradient, out[2] weight gradient, in FLOPs.
+//   forward: per pixel tile 2 * 128 pixels * Cout * (9 * active channels, padded to the 32-deep stage);
+//   data gradient: per class tile 2 * 128 pixels * (active channels padded to a 32-row block) * Cout * taps of the class;
+//   weight gradient: per (channel group, active pixel tile) 2 * 128 pixels * Cout * (WA_NT * 32 columns).
+// Reads the list headers back (synchronises with `stream`): measurement only, never on the training path.
+extern "C" int lidog_conv2d_support_work(const int32_t *act, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                                         double *out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(act && out && Cin >= 1 && Cin <= 128, "conv2d_support_work: bad arguments");
+    ActLayout L = act_layout(B, Cin, H, W);
+    out[0] = out[1] = out[2] = 0.0;
+    std::vector<int32_t> head;
+    auto heads = [&](int64_t off, int tiles, int pitch) -> int {
+        head.assign((size_t)(tiles > 0 ? tiles : 1), 0);
+        if (tiles <= 0) return 0;
+        LIDOG_CHECK_HIP(hipMemcpy2DAsync(head.data(), sizeof(int32_t), act + off, (size_t)pitch * sizeof(int32_t),
+                                         sizeof(int32_t), (size_t)tiles, hipMemcpyDeviceToHost, st));
+        LIDOG_CHECK_HIP(hipStreamSynchronize(st));
+        return 0;
+    };
+    if (int rc = heads(L.fwd_off, L.fwd_tiles, Cin + 1)) return rc;
+    for (int t = 0; t < L.fwd_tiles; ++t) {
+        const int Kp = (head[t] * 9 + C2_KB - 1) / C2_KB * C2_KB;
+        out[0] += 2.0 * IG_T * Cout * Kp;
+    }
+    for (int cls = 0; cls < 4; ++cls) {
+        const int nt = ((cls >> 1) ? 2 : 1) * ((cls & 1) ? 2 : 1);
+        if (int rc = heads(L.dgrad_off[cls], L.dgrad_tiles[cls], Cin + 1)) return rc;
+        for (int t = 0; t < L.dgrad_tiles[cls]; ++t)
+            out[1] += 2.0 * IG_T * ((head[t] + 31) / 32 * 32) * (double)Cout * nt;
+    }
+    if (int rc = heads(L.glists_off, L.groups, L.fwd_tiles + 1)) return rc;
+    for (int g = 0; g < L.groups; ++g) out[2] += 2.0 * IG_T * (double)head[g] * Cout * (WA_NT * 32);
     return 0;
 }

@@ -1,0 +1,564 @@
+// Output-stationary sparse convolution for 3^3 kernels on one coordinate map (MinkowskiConvolution(kernel_size=3,
+// stride=1) of the BasicBlocks, utils/models/minkunet_bev.py:425-439 / resnet_block.py:8-56): the product rows `T` of
+// the two-pass path (gathered GEMM -> T [P, Cout] -> per-row reduction) never exist.
+//
+// A workgroup owns 128 OUTPUT rows x 32 NT columns and walks the kernel offsets k in ascending order: for every k it
+// gathers the rows' neighbours nbr[k][row] (a missing neighbour is a zero row), multiplies by W[k] into a scratch
+// accumulator -- the same k-ordered fmaf chain from zero as a product row of the two-pass path -- and adds that
+// accumulator to the running sum of the rows: out = ((0 + T_k0) + T_k1) + ..., the additions of the reduction pass in
+// the same order.  Results are therefore bit-identical to the two-pass path (and to oracle/me_oracle.c) up to the sign
+// of a zero; what changes is the traffic (no 4 P Cout bytes written and read back: 1.2 GB per stride-1 96-channel
+// layer at batch 4) and the length of a workgroup's matrix phase (every offset of the tile instead of one).
+//
+// Done naively this multiplies zero rows 2.2 x as often as real ones (a LiDAR voxel has 4.5 of its 27 neighbours).
+// Rows are therefore SORTED by their neighbour mask first (lidog_kernel_map_sorted: 27-bit mask with the rarest offset
+// as the most significant bit, stable radix sort), which puts rows with the same neighbour pattern into the same tile:
+// a tile skips every offset none of its rows has, a wave skips the matrix work of every offset none of its 32 rows
+// has.  Measured on the bench scans: 85 % of the 32-row x offset blocks that are multiplied are real pairs at tensor
+// strides 1 and 2 (80 % at strides 4 / 8, 69 % at 16).
+//
+// The data gradient of such a convolution is the same sum over the MIRRORED offsets (the map is symmetric: row o has
+// input neighbour i at offset k  <=>  row i has neighbour o at offset K-1-k), so the same sorted rows and masks serve
+// both directions: `reverse` walks the bits from the top and takes the transposed weights of offset K-1-k.
+#include <stdlib.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+#include "stats_tail.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define OS_TM 128
+#define OS_BK 32
+#define OS_SA 33
+#define OS_MAXK 27
+
+// ------------------------------------------------------------------ sorted rows of a map
+// pos[k]: bit position of offset k in the sort key = number of offsets that occur MORE often (ties: lower k first), so
+// the rarest offset is the most significant bit
+__global__ void k_os_bitpos(const int64_t *__restrict__ k_off, int K, int32_t *__restrict__ pos) {
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    const int64_t mine = k_off[k + 1] - k_off[k];
+    int p = 0;
+    for (int j = 0; j < K; ++j) {
+        const int64_t c = k_off[j + 1] - k_off[j];
+        if (c > mine || (c == mine && j < k)) ++p;
+    }
+    pos[k] = p;
+}
+
+__global__ __launch_bounds__(256) void k_os_keys(const int32_t *__restrict__ nbr, int64_t n, int K,
+                                                 const int32_t *__restrict__ pos, uint32_t *__restrict__ keys,
+                                                 int32_t *__restrict__ rows, uint32_t *__restrict__ masks) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    uint32_t key = 0, m = 0;
+    for (int k = 0; k < K; ++k) {
+        const uint32_t has = nbr[(int64_t)k * n + r] >= 0 ? 1u : 0u;
+        m |= has << k;
+        key |= has << pos[k];
+    }
+    keys[r] = key;
+    rows[r] = (int32_t)r;
+    masks[r] = m;
+}
+
+// one wave per 32 sorted rows: the OR of their masks; rows past the end of the map are -1 in `perm`
+__global__ __launch_bounds__(256) void k_os_wave_masks(const uint32_t *__restrict__ masks, int32_t *__restrict__ perm,
+                                                       int64_t n, int64_t n_pad, uint32_t *__restrict__ wave_masks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t m = 0;
+    if (i < n) m = masks[perm[i]];
+    else if (i < n_pad) perm[i] = -1;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d);
+    if (i < n_pad && (threadIdx.x & 31) == 0) wave_masks[i >> 5] = m;
+}
+
+// launch order of the tiles: the ones with the most (wave, offset) blocks to multiply first, so that the grid ends on its
+// shortest workgroups (a tile walks 5 to 27 offsets).  key = 127 - blocks, sorted ascending (stable: ties by tile id).
+__global__ __launch_bounds__(256) void k_os_tile_keys(const uint32_t *__restrict__ wave_masks, int n_tiles,
+                                                      uint32_t *__restrict__ keys, int32_t *__restrict__ ids) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int w = __popc(wave_masks[4 * t]) + __popc(wave_masks[4 * t + 1]) + __popc(wave_masks[4 * t + 2]) +
+                  __popc(wave_masks[4 * t + 3]);
+    keys[t] = (uint32_t)(127 - w);
+    ids[t] = t;
+}
+
+static int64_t os_pad(int64_t n) { return (n + OS_TM - 1) / OS_TM * OS_TM; }
+
+static size_t os_sort_temp(int64_t n) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                       (const int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+// bytes of workspace lidog_kernel_map_sorted needs for a map of n rows
+extern "C" int64_t lidog_kernel_map_sorted_ws(int64_t n) {
+    if (n <= 0) return 256;
+    return (int64_t)os_sort_temp(n) + 4 * 4 * n + 8 * (os_pad(n) / OS_TM) + 4096;
+}
+
+// perm [pad128(n)] int32: the rows in sorted order (-1 behind the last one); wave_masks [pad128(n) / 32] uint32: the OR
+// of the neighbour masks of every 32 sorted rows (four consecutive words = one 128-row tile); tile_order
+// [pad128(n) / 128] int32: the tiles in launch order (most blocks first)
+extern "C" int lidog_kernel_map_sorted(const int32_t *nbr, int64_t n, int32_t K, const int64_t *k_off, int32_t *perm,
+                                       uint32_t *wave_masks, int32_t *tile_order, void *ws, int64_t ws_bytes,
+                                       void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(K >= 1 && K <= OS_MAXK, "kernel_map_sorted: 1 <= K <= %d", OS_MAXK);
+    if (n == 0) return 0;
+    LIDOG_REQUIRE(nbr && k_off && perm && wave_masks && tile_order && ws && n < ((int64_t)1 << 31),
+                  "kernel_map_sorted: bad arguments");
+    LIDOG_REQUIRE(ws_bytes >= lidog_kernel_map_sorted_ws(n), "kernel_map_sorted: workspace too small");
+    char *p = (char *)ws;
+    int32_t *pos = (int32_t *)p;                  p += 256;
+    uint32_t *keys = (uint32_t *)p;               p += 4 * n;
+    uint32_t *keys_out = (uint32_t *)p;           p += 4 * n;
+    int32_t *rows = (int32_t *)p;                 p += 4 * n;
+    uint32_t *masks = (uint32_t *)p;              p += 4 * n;
+    p = (char *)(((uintptr_t)p + 255) / 256 * 256);
+    size_t temp = os_sort_temp(n);
+    k_os_bitpos<<<1, 32, 0, st>>>(k_off, K, pos);
+    k_os_keys<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(nbr, n, K, pos, keys, rows, masks);
+    LIDOG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs((void *)p, temp, keys, keys_out, rows, perm, (int)n, 0, K, st));
+    const int64_t n_pad = os_pad(n);
+    k_os_wave_masks<<<(unsigned)cdiv64(n_pad, 256), 256, 0, st>>>(masks, perm, n, n_pad, wave_masks);
+    const int n_tiles = (int)(n_pad / OS_TM);
+    uint32_t *tkeys = keys, *tkeys_out = keys_out;      // the row keys are done with: reuse their arrays
+    int32_t *tids = rows;
+    k_os_tile_keys<<<(unsigned)cdiv64(n_tiles, 256), 256, 0, st>>>(wave_masks, n_tiles, tkeys, tids);
+    LIDOG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs((void *)p, temp, tkeys, tkeys_out, tids, tile_order, n_tiles, 0, 7, st));
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ the convolution
+template <int NT>
+__device__ __forceinline__ void os_frag_load(const float *p, float (&f)[NT]) {
+    if constexpr (NT == 4) {
+        float4 v = *reinterpret_cast<const float4 *>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else if constexpr (NT == 2) {
+        float2 v = *reinterpret_cast<const float2 *>(p);
+        f[0] = v.x; f[1] = v.y;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f[t] = p[t];
+    }
+}
+
+// What the epilogue adds to the store of the rows (the jobs of the reduction pass's statistics forms, sconv.hip):
+//   mode 1  BatchNorm statistics of the result: per-channel (sum x, sum x^2) in fp64, one partial row per tile, added in
+//           a fixed order and finalised by the last workgroup to arrive (stats_tail.h)        = k_sconv_reduce_rows4_stats
+//   mode 2  the result is the complete gradient dy of the BatchNorm (+ReLU) output that `pre` is the input of:
+//           (sum dy', sum dy' xhat), dy' = dy masked by that layer's ReLU (mask from its bits, its saved output, or
+//           recomputed from pre with the forward pass's own expression)                        = ..._rows4_bwdstats
+struct OsStats {
+    int mode;
+    StatsTail tail;
+    const float *pre, *relu_y;
+    const uint32_t *rbits;
+    const float *mean, *invstd, *rw, *rb;
+};
+
+// MFMA 32x32x2 lane maps as in sconv_mfma.hip: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
+// D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5).  MFMA column tile t of a wave = columns {li * NT + t}.
+template <int NT, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__restrict__ A, const int32_t *__restrict__ nbr,
+                                                       int64_t n, int K, const int32_t *__restrict__ perm,
+                                                       const uint32_t *__restrict__ wave_masks,
+                                                       const int32_t *__restrict__ tile_order,
+                                                       const float *__restrict__ W, int reverse,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ addend, int Cin, int Cout,
+                                                       float *__restrict__ out, OsStats st) {
+    constexpr int TN = 32 * NT;
+    constexpr int BV = (OS_BK * TN / 4) / 256;
+    __shared__ float As[OS_TM * OS_SA];
+    __shared__ __attribute__((aligned(16))) float Bs[OS_BK * TN];
+    __shared__ int32_t s_row[OS_TM];
+    __shared__ int32_t s_nbr[OS_MAXK * OS_TM];   // neighbour row of (offset, tile row), -1 = none
+
+    const int tile = tile_order[blockIdx.x];   // heaviest tiles first
+    const int col0 = blockIdx.y * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+
+#ifdef OS_EXP_NOSKIP
+    const uint32_t wm = 0xFFFFFFFFu;
+#else
+    const uint32_t wm = wave_masks[tile * 4 + wave];
+#endif
+    const uint32_t tm = wave_masks[tile * 4] | wave_masks[tile * 4 + 1] | wave_masks[tile * 4 + 2] | wave_masks[tile * 4 + 3];
+    if (tid < OS_TM) s_row[tid] = perm[(int64_t)tile * OS_TM + tid];
+    __syncthreads();
+    // neighbour table of the tile (one gather per (offset, row), all issued before use); offsets the tile does not
+    // have are never read back
+    for (int e = tid; e < K * OS_TM; e += 256) {
+        const int k = e / OS_TM, r = e - k * OS_TM;
+        const int row = s_row[r];
+        s_nbr[e] = (row >= 0 && ((tm >> k) & 1u)) ? nbr[(int64_t)k * n + row] : -1;
+    }
+    __syncthreads();
+
+    f32x16 acc[NT], part[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc[t][e] = 0.f;
+            part[t][e] = 0.f;
+        }
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = -0.0f;
+    if (bias) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = bias[col0 + li * NT + t];
+    }
+
+    // staging: thread handles the float4 (tid & 7) of tile rows (tid >> 3) + 32 j
+    float4 ra[4], rb0, rb1, rb2, rb3;
+    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *a_row[4];
+    bool ok_cur[4], ok_nxt[4];
+    const int q4 = (tid & 7) * 4;
+#define OS_LOADB(J, R)                                                                     \
+    if constexpr (BV > J) {                                                                \
+        int f = tid + 256 * J;                                                             \
+        int kk = f / (TN / 4), c4 = f % (TN / 4);                                          \
+        R = *reinterpret_cast<const float4 *>(Bk + (size_t)(kb + kk) * Cout + c4 * 4);      \
+    }
+#define OS_STOREB(J, R) \
+    if constexpr (BV > J) *reinterpret_cast<float4 *>(&Bs[(tid + 256 * J) * 4]) = R;
+    auto rows_of = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int src = s_nbr[k * OS_TM + (tid >> 3) + 32 * j];
+#ifdef OS_EXP_NOGATHER
+            src = (src < 0) ? -1 : (tile * OS_TM + (tid >> 3) + 32 * j) % (int)n;   // contiguous rows instead of neighbours
+#endif
+            ok_nxt[j] = src >= 0;
+            a_row[j] = A + (size_t)(src < 0 ? 0 : src) * Cin + q4;
+        }
+    };
+    auto load_chunk = [&](int k, int kb) {
+        const float *Bk = W + (size_t)(reverse ? K - 1 - k : k) * Cin * Cout + col0;
+#ifndef OS_EXP_NOA
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4 *>(a_row[j] + kb);
+#endif
+#ifndef OS_EXP_NOB
+        OS_LOADB(0, rb0) OS_LOADB(1, rb1) OS_LOADB(2, rb2) OS_LOADB(3, rb3)
+#endif
+    };
+    auto next_offset = [&](uint32_t rem) { return reverse ? 31 - __builtin_clz(rem) : __builtin_ctz(rem); };
+
+#if defined(OS_EXP_NOA)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = make_float4(1.f, 2.f, 3.f, 4.f);
+#endif
+    uint32_t rem = tm;
+    if (rem != 0) {
+        int k_cur = next_offset(rem);
+        rem &= ~(1u << k_cur);
+        int kb_cur = 0;
+        rows_of(k_cur);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ok_cur[j] = ok_nxt[j];
+        load_chunk(k_cur, 0);
+        for (;;) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = tid + 256 * j;
+                const int o = (f >> 3) * OS_SA + (f & 7) * 4;
+                const bool ok = ok_cur[j];
+                As[o] = ok ? ra[j].x : 0.f;
+                As[o + 1] = ok ? ra[j].y : 0.f;
+                As[o + 2] = ok ? ra[j].z : 0.f;
+                As[o + 3] = ok ? ra[j].w : 0.f;
+            }
+            OS_STOREB(0, rb0) OS_STOREB(1, rb1) OS_STOREB(2, rb2) OS_STOREB(3, rb3)
+            __syncthreads();
+            // the chunk after this one: the next 32 channels of this offset, or the first 32 of the tile's next offset;
+            // past the end the current chunk is fetched again (an unconditional load: a branch around the staging
+            // registers sends them through scratch memory)
+            const bool last_of_offset = kb_cur + OS_BK >= Cin;
+            const bool more = !last_of_offset || rem != 0;
+            int k_nxt = k_cur, kb_nxt = kb_cur + OS_BK;
+            if (last_of_offset) {
+                kb_nxt = 0;
+                if (rem != 0) {
+                    k_nxt = next_offset(rem);
+                    rem &= ~(1u << k_nxt);
+                    rows_of(k_nxt);
+                }
+            }
+            load_chunk(k_nxt, kb_nxt);
+            if ((wm >> k_cur) & 1u) {
+                const float *arow = &As[(wave * 32 + li) * OS_SA + kh];
+                const float *bcol = &Bs[kh * TN + li * NT];
+                float bq0[NT], bq1[NT], bn0[NT], bn1[NT], a0, a1, an0, an1;
+                os_frag_load<NT>(bcol, bq0);
+                os_frag_load<NT>(bcol + 2 * TN, bq1);
+                a0 = arow[0];
+                a1 = arow[2];
+#pragma unroll
+                for (int j = 0; j < OS_BK / 4; ++j) {
+                    if (j + 1 < OS_BK / 4) {
+                        os_frag_load<NT>(bcol + (4 * j + 4) * TN, bn0);
+                        os_frag_load<NT>(bcol + (4 * j + 6) * TN, bn1);
+                        an0 = arow[4 * j + 4];
+                        an1 = arow[4 * j + 6];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) part[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], part[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) part[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], part[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 1 < OS_BK / 4) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            bq0[t] = bn0[t];
+                            bq1[t] = bn1[t];
+                        }
+                        a0 = an0;
+                        a1 = an1;
+                    }
+                }
+#ifndef OS_EXP_NOADD
+                if (last_of_offset) {   // the offset's product rows are complete: the reduction pass's addition
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            acc[t][e] += part[t][e];
+                            part[t][e] = 0.f;
+                        }
+                }
+#endif
+            }
+            if (!more) break;
+            if (last_of_offset) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ok_cur[j] = ok_nxt[j];
+            }
+            k_cur = k_nxt;
+            kb_cur = kb_nxt;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // the last, redundant prefetch is drained once (vmcnt 0), see sconv_mfma.hip
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] += bv[t];
+    // per-lane statistics of this lane's 16 rows x NT columns (fp64), rows past the end of the map left out
+    double s0[NT], s1[NT];
+    float bn_m[NT], bn_is[NT], bn_w[NT], bn_b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        s0[t] = s1[t] = 0.0;
+        bn_m[t] = 0.f; bn_is[t] = 1.f; bn_w[t] = 0.f; bn_b[t] = 1.f;
+    }
+    const bool from_x = st.mode == 2 && st.relu_y == nullptr && st.rw != nullptr;
+    const bool has_relu = st.mode == 2 && (st.relu_y != nullptr || from_x || st.rbits != nullptr);
+    if (st.mode == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bn_m[t] = st.mean[col0 + li * NT + t];
+            bn_is[t] = st.invstd[col0 + li * NT + t];
+            if (from_x) {
+                bn_w[t] = st.rw[col0 + li * NT + t];
+                bn_b[t] = st.rb[col0 + li * NT + t];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int dst = s_row[r];
+        if (dst >= 0) {
+            const size_t at = (size_t)dst * Cout + col0 + li * NT;
+            float *o = out + at;
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[t][e];
+            if (addend) {
+                const float *ad = addend + at;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] += ad[t];
+            }
+            if constexpr (NT == 4) {
+                *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if constexpr (NT == 2) {
+                *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[t] = v[t];
+            }
+            if (st.mode == 1) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    s0[t] += (double)v[t];
+                    s1[t] += (double)v[t] * (double)v[t];
+                }
+            } else if (st.mode == 2) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float x = st.pre[at + t];
+                    float y = 1.f;
+                    if (st.rbits) {
+                        const size_t el = at + t;                  // bit (el & 3) of nibble ((el >> 2) & 7) of word el >> 5
+                        y = (float)((st.rbits[el >> 5] >> (4 * (int)((el >> 2) & 7) + (int)(el & 3))) & 1u);
+                    } else if (st.relu_y) {
+                        y = st.relu_y[at + t];
+                    } else if (from_x) {   // the forward pass's pre-activation, bit for bit (bn.hip:k_bn_apply4)
+                        y = (x - bn_m[t]) * bn_is[t] * bn_w[t] + bn_b[t];
+                    }
+                    const float g = (has_relu && !(y > 0.f)) ? 0.f : v[t];   // = bn.hip:red_terms<1>
+                    const float xh = (x - bn_m[t]) * bn_is[t];
+                    s0[t] += (double)g;
+                    s1[t] += (double)g * (double)xh;
+                }
+            }
+        }
+    }
+    if (st.mode != 0) {
+        // the tile's column sums: the two row halves of a wave (lanes l, l + 32), then the four waves in order
+        __syncthreads();   // As is free now: it carries the waves' sums
+        double *red = reinterpret_cast<double *>(As);   // [4 waves][2][TN]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s0[t] += __shfl_xor(s0[t], 32);
+            s1[t] += __shfl_xor(s1[t], 32);
+            if (kh == 0) {
+                red[(wave * 2 + 0) * TN + li * NT + t] = s0[t];
+                red[(wave * 2 + 1) * TN + li * NT + t] = s1[t];
+            }
+        }
+        __syncthreads();
+        const int C2 = 2 * st.tail.C;
+        if (tid < 2 * TN) {
+            const int which = tid / TN, c = tid - which * TN;
+            const double v = ((red[(0 * 2 + which) * TN + c] + red[(1 * 2 + which) * TN + c]) +
+                              red[(2 * 2 + which) * TN + c]) + red[(3 * 2 + which) * TN + c];
+            lidog_store_sc1(st.tail.partial + (size_t)tile * C2 + which * st.tail.C + col0 + c, v);
+        }
+        lidog_stats_tail_rows(st.tail, tile, (int)gridDim.x, (int)gridDim.y);
+    }
+}
+
+static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const int32_t *perm,
+                     const uint32_t *wave_masks, const int32_t *tile_order, const float *W, int reverse,
+                     const float *bias, const float *addend, int Cin, int Cout, float *out, const OsStats &stats,
+                     hipStream_t st) {
+    LIDOG_REQUIRE(K >= 1 && K <= OS_MAXK && Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0,
+                  "sconv_os: K <= %d, channel counts multiples of 32 (got K %d, %d -> %d)", OS_MAXK, K, Cin, Cout);
+    LIDOG_REQUIRE(A && nbr && perm && wave_masks && tile_order && W && out, "sconv_os: null argument");
+    int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
+    static int force_nt = -1;   // A/B: LIDOG_OS_NT = column tiles of 32 per workgroup where the width allows it
+    if (force_nt < 0) {
+        const char *e = getenv("LIDOG_OS_NT");
+        force_nt = e ? atoi(e) : 0;
+    }
+    if (force_nt >= 1 && force_nt <= 4 && Cout % (32 * force_nt) == 0) nt = force_nt;
+    dim3 grid((unsigned)(os_pad(n) / OS_TM), (unsigned)(Cout / (32 * nt)));
+#define OS_LAUNCH(NT_, MW_)                                                                                         \
+    k_sconv_os_mfma<NT_, MW_><<<grid, 256, 0, st>>>(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, addend, \
+                                                    Cin, Cout, out, stats)
+    static int minw = -1;   // A/B: LIDOG_OS_MINW=3 compiles the 96- / 128-column kernels for three waves per SIMD (spills)
+    if (minw < 0) {
+        const char *e = getenv("LIDOG_OS_MINW");
+        minw = e ? atoi(e) : 2;
+    }
+    switch (nt) {
+        case 4:
+            if (minw >= 3) OS_LAUNCH(4, 3);
+            else OS_LAUNCH(4, 2);
+            break;
+        case 3:
+            if (minw >= 3) OS_LAUNCH(3, 3);
+            else OS_LAUNCH(3, 2);
+            break;
+        case 2: OS_LAUNCH(2, 4); break;
+        default: OS_LAUNCH(1, 4);
+    }
+#undef OS_LAUNCH
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// out [n, Cout] = sum over k ascending of A[nbr[k][row]] W[k]  (+ bias) (+ addend), rows in canonical order.
+// reverse != 0: the data gradient over a symmetric 3^3 map: offsets walked from the top, weights W[K-1-k] (pass the
+// transposed kernels [K][Cout][Cin] with Cin / Cout swapped).  perm / wave_masks / tile_order: lidog_kernel_map_sorted.
+extern "C" int lidog_sconv_os(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                              const uint32_t *wave_masks, const int32_t *tile_order, const float *W, int32_t reverse,
+                              const float *bias, const float *addend, int32_t Cin, int32_t Cout, float *out,
+                              void *stream) {
+    if (n == 0) return 0;
+    OsStats stats = {};
+    return os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, addend, Cin, Cout, out, stats,
+                     (hipStream_t)stream);
+}
+
+// doubles of workspace of the two statistics forms: one partial row per 128-row tile + the group rows of the tail
+extern "C" int64_t lidog_sconv_os_stats_ws(int64_t n, int32_t C) {
+    return (os_pad(n) / OS_TM + STATS_MAX_GROUPS) * (int64_t)2 * C;
+}
+
+// Forward convolution + the BatchNorm statistics of its result (= lidog_sconv_gemm + lidog_sconv_reduce_rows_stats):
+// sums [2 Cout + 1], ws: lidog_sconv_os_stats_ws doubles; count / eps / momentum / mean / ... as lidog_bn_stats.
+extern "C" int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                                    const uint32_t *wave_masks, const int32_t *tile_order, const float *W,
+                                    const float *bias, int32_t Cin, int32_t Cout, float *out, double *sums, double *ws,
+                                    double count, float eps, float momentum, float *mean, float *invstd,
+                                    float *running_mean, float *running_var, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(sums && ws, "sconv_os_stats: sums / workspace missing");
+    LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_os_stats: finalising needs the row count");
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * Cout + 1), st) == hipSuccess ? 0 : 1;
+    LIDOG_REQUIRE(os_pad(n) / OS_TM <= (int64_t)STATS_MAX_GROUPS * STATS_GROUP, "sconv_os_stats: too many tiles");
+    OsStats stats = {};
+    stats.mode = 1;
+    BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
+    if (lidog_stats_tail_make(&stats.tail, ws, sums, count, Cout, fin, st)) return 1;
+    int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats, st);
+    if (rc) return rc;
+    return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);
+}
+
+// Data gradient of the convolution over its (symmetric) map + the BatchNorm-backward statistics of the layer that
+// produced the rows it completes (= lidog_sconv_gemm with the transposed kernels + lidog_sconv_reduce_rows_bwdstats).
+// G [n, Cg]: gradient of the convolution's output; Wt [K][Cg][Cx]; gx [n, Cx] = result (+ addend); pre / relu_* /
+// mean / invstd / sums / dw / db: the producer's, as lidog_sconv_reduce_rows_bwdstats.
+extern "C" int lidog_sconv_os_bwdstats(const float *G, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                                       const uint32_t *wave_masks, const int32_t *tile_order, const float *Wt,
+                                       const float *addend, int32_t Cg, int32_t Cx, float *gx, const float *pre,
+                                       const float *relu_y, const uint32_t *relu_bits, const float *mean,
+                                       const float *invstd, const float *relu_w, const float *relu_b, double *sums,
+                                       double *ws, double count, float *dw, float *db, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(pre && mean && invstd && sums && ws, "sconv_os_bwdstats: null argument");
+    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) &&
+                      (relu_y != nullptr) + (relu_w != nullptr) + (relu_bits != nullptr) <= 1,
+                  "sconv_os_bwdstats: pass at most one of relu_y, relu_bits, (relu_w, relu_b)");
+    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * Cx + 1), st) == hipSuccess ? 0 : 1;
+    LIDOG_REQUIRE(os_pad(n) / OS_TM <= (int64_t)STATS_MAX_GROUPS * STATS_GROUP, "sconv_os_bwdstats: too many tiles");
+    OsStats stats = {};
+    stats.mode = 2;
+    stats.pre = pre; stats.relu_y = relu_y; stats.rbits = relu_bits;
+    stats.mean = mean; stats.invstd = invstd; stats.rw = relu_w; stats.rb = relu_b;
+    BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
+    if (lidog_stats_tail_make(&stats.tail, ws, sums, count, Cx, fin, st)) return 1;
+    int rc = os_launch(G, nbr, n, K, perm, wave_masks, tile_order, Wt, 1, nullptr, addend, Cg, Cx, gx, stats, st);
+    if (rc) return rc;
+    return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);
+}

@@ -19,7 +19,7 @@
 #include "common.h"
 
 #define STATS_GROUP 32
-#define STATS_MAX_GROUPS 64   // rows of workspace behind the partial rows; 64 * 32 = 2048 workgroups at most
+#define STATS_MAX_GROUPS 128  // rows of workspace behind the partial rows; 128 * 32 = 4096 partial rows at most
 
 typedef __attribute__((address_space(1))) unsigned long long lidog_gu64;
 typedef __attribute__((address_space(1))) unsigned int lidog_gu32;
@@ -71,33 +71,25 @@ __device__ __forceinline__ double lidog_rows_sum_sc1(const double *base, int r0,
     return s;
 }
 
-// Called by EVERY thread of EVERY workgroup (256 threads, 1-D grid) at the end of the kernel.  `writer`: this thread
-// holds the workgroup's totals of channels 4 c4 .. 4 c4 + 3 (a[0..3] first sums, a[4..7] second sums).
-__device__ __forceinline__ void lidog_stats_tail(const StatsTail &t, bool writer, int c4, const double (&a)[8]) {
+// Second half of the tail, for a workgroup whose slice of partial row `b` (of `nb` rows) has been stored with
+// lidog_store_sc1 by its threads: `per_row` workgroups contribute to a row (column tiles of a 2-D grid; 1 otherwise).
+// Called by EVERY thread of EVERY workgroup of the launch.
+__device__ __forceinline__ void lidog_stats_tail_rows(const StatsTail &t, int b, int nb, int per_row) {
     __shared__ int s_last;
     const int C = t.C, C2 = 2 * C;
-    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
     const int ng = (nb + STATS_GROUP - 1) / STATS_GROUP;
     const int g = b / STATS_GROUP;
     const int g0 = g * STATS_GROUP;
     const int gsize = (nb - g0 < STATS_GROUP) ? nb - g0 : STATS_GROUP;
-    if (writer) {
-        double *dst = t.partial + (size_t)b * C2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lidog_store_sc1(dst + c4 * 4 + j, a[j]);
-            lidog_store_sc1(dst + C + c4 * 4 + j, a[4 + j]);
-        }
-    }
     if (!t.tickets) return;   // A/B switch (LIDOG_STATS_TAIL=0): bn.hip:k_sums_finish adds the rows in a launch of its own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the barrier
     __syncthreads();
     if (threadIdx.x == 0) {
         int last = 1;
-        if (gsize > 1) {
+        if (gsize * per_row > 1) {
             unsigned old = __hip_atomic_fetch_add((lidog_gu32 *)(t.tickets + 1 + g), 1u, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
-            last = old == (unsigned)(gsize - 1);
+            last = old == (unsigned)(gsize * per_row - 1);
         }
         s_last = last;
     }
@@ -105,7 +97,7 @@ __device__ __forceinline__ void lidog_stats_tail(const StatsTail &t, bool writer
     if (!s_last) return;
     // ---- last workgroup of group g: the group's rows, ascending
     double *grow = t.partial + (size_t)(nb + g) * C2;
-    for (int col = threadIdx.x; col < C2; col += 256)
+    for (int col = threadIdx.x; col < C2; col += blockDim.x)
         lidog_store_sc1(grow + col, lidog_rows_sum_sc1(t.partial, g0, gsize, C2, col));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -121,7 +113,7 @@ __device__ __forceinline__ void lidog_stats_tail(const StatsTail &t, bool writer
     if (!s_last) return;
     // ---- last group finisher: the group rows, ascending; then what follows the reduction
     const double *grows = t.partial + (size_t)nb * C2;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const double s0 = lidog_rows_sum_sc1(grows, 0, ng, C2, c);
         const double s1 = lidog_rows_sum_sc1(grows, 0, ng, C2, C + c);
         t.sums[c] = s0;
@@ -132,8 +124,24 @@ __device__ __forceinline__ void lidog_stats_tail(const StatsTail &t, bool writer
     }
     if (threadIdx.x == 0 && t.count > 0) t.sums[C2] = t.count;
     // ticket words back to zero for the next launch on this stream (every add of this launch has returned by now)
-    for (int i = threadIdx.x; i < 1 + ng; i += 256)
+    for (int i = threadIdx.x; i < 1 + ng; i += blockDim.x)
         __hip_atomic_store((lidog_gu32 *)(t.tickets + i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by EVERY thread of EVERY workgroup (256 threads, 1-D grid) at the end of the kernel.  `writer`: this thread
+// holds the workgroup's totals of channels 4 c4 .. 4 c4 + 3 (a[0..3] first sums, a[4..7] second sums).
+__device__ __forceinline__ void lidog_stats_tail(const StatsTail &t, bool writer, int c4, const double (&a)[8]) {
+    const int C = t.C, C2 = 2 * C;
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    if (writer) {
+        double *dst = t.partial + (size_t)b * C2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lidog_store_sc1(dst + c4 * 4 + j, a[j]);
+            lidog_store_sc1(dst + C + c4 * 4 + j, a[4 + j]);
+        }
+    }
+    lidog_stats_tail_rows(t, b, nb, 1);
 }
 
 // ticket words of the launches queued on `stream` (zeroed when created; launches that share them must be ordered, which

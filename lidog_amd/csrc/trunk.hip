@@ -22,7 +22,7 @@ namespace {
 enum { TC_KIND, TC_MAP, TC_CIN, TC_COUT, TC_K, TC_W, TC_WT, TC_GW, TC_BIAS, TC_GBIAS, TC_BNW, TC_BNB, TC_BNRM, TC_BNRV,
        TC_GBNW, TC_GBNB, TC_ITEMS, TC_NITEMS, TC_ITEMOFF, TC_COLS = 20 };
 enum { TM_K, TM_NIN, TM_NOUT, TM_P, TM_PAIR_IN, TM_PAIR_OUT, TM_RP_OUT, TM_RL_OUT, TM_RP_IN, TM_RL_IN, TM_TILES,
-       TM_NTILES, TM_NBR, TM_IDENT, TM_COLS = 16 };
+       TM_NTILES, TM_NBR, TM_IDENT, TM_PERM, TM_WMASK, TM_ORDER, TM_COLS = 20 };
 enum { TO_TYPE, TO_CONV, TO_IN, TO_OUT, TO_RELU, TO_RES, TO_FOLD, TO_B, TO_COLS = 8 };
 enum { TB_LEVEL, TB_CH, TB_EXT, TB_COLS = 4 };
 enum { REC_PRE, REC_MEAN, REC_INVSTD, REC_BITS, REC_COLS = 4 };   // REC_BITS: arena offset + 1 of the ReLU bit mask, 0 = none
@@ -211,6 +211,11 @@ struct GemmRec {
     double flops, bytes;
 };
 bool g_timing = false;
+// algorithmic bytes of the two other HBM-heavy families while timing is on (DESIGN.md section 3 formulas; bench.py sets
+// them against the PMC traffic of the same families): [0] MFMA weight-gradient launches, [1] their bytes
+// 4 P (Cin + Cout) + 4 K Cin Cout (1 + 2 slabs / K), [2] per-row reduction launches, [3] their bytes
+// 4 (P + N) C + 4 (P + N) (+ 8 N C for the saved input and mask / addend the backward-statistics form also reads)
+double g_work[4] = {0, 0, 0, 0};
 std::vector<GemmRec> g_recs;
 std::vector<hipEvent_t> g_spare;
 
@@ -341,7 +346,20 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         float *f_rm = sync ? nullptr : rm, *f_rv = sync ? nullptr : rv;
         const float f_eps = sync ? 0.f : eps, f_mom = sync ? 0.f : mom;
         bool stats_done = false;
-        if (kind == KIND_K3 || kind == KIND_DOWN) {
+        // sorted rows of a sparse symmetric 3^3 map: the output-stationary kernel (csrc/sconv_os.hip), no product rows
+        const bool os = kind == KIND_K3 && m[TM_PERM] && m[TM_WMASK] && m[TM_ORDER] && m[TM_NBR] && m[TM_NIN] == m[TM_NOUT] &&
+                        Cin % 32 == 0 && Cout % 32 == 0 && lidog_get_sparse_core() == 1;
+        if (os && bn) {
+            double *ws = (double *)sc.take(lidog_sconv_os_stats_ws(n, Cout) * 8);
+            TRY(lidog_sconv_os_stats(x, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
+                                     P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, bias, Cin, Cout,
+                                     pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
+            stats_done = true;
+        } else if (os) {
+            TRY(lidog_sconv_os(x, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
+                               P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, 0, bias, nullptr, Cin,
+                               Cout, pre, stream));
+        } else if (kind == KIND_K3 || kind == KIND_DOWN) {
             // gathered GEMM into product rows, per-row reduction (+ BatchNorm statistics in its epilogue)
             float *T = (float *)sc.take(m[TM_P] * Cout * 4);
             if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T, nullptr, stream))
@@ -354,6 +372,10 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                 stats_done = true;
             } else {
                 TRY(lidog_sconv_reduce_rows(T, rp, rl, n, Cout, bias, nullptr, pre, stream));
+            }
+            if (g_timing && !ctx.dry) {
+                g_work[2] += 1;
+                g_work[3] += 4.0 * ((double)m[TM_P] + n) * Cout + 4.0 * ((double)m[TM_P] + n);
             }
         } else if (kind == KIND_UP) {
             // transposed 2^3 stride 2: every fine row has exactly one pair, the GEMM scatters straight into the output
@@ -617,6 +639,10 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             }
             TRY(lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
                                   P<const int32_t>(c[TC_ITEMOFF]), K, Cin, Cout, partial, P<float>(c[TC_GW]), st));
+            if (g_timing && !ctx.dry && Cin % 32 == 0 && Cout % 32 == 0) {
+                g_work[0] += 1;
+                g_work[1] += 4.0 * (double)m[TM_P] * (Cin + Cout) + 4.0 * (double)Cin * Cout * (K + 2.0 * (slabs > 1 ? slabs : 1));
+            }
             return 0;
         };
         const bool behind = lane && !wgrad_first;
@@ -639,6 +665,25 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 float *gx = target(in_b);
                 if (int rc = gemm(ctx, m, gout, n, g_out, Wt, nullptr, Cout, Cin, gx, g_in, stream)) return rc;
                 if (int rc = commit(in_b, gx)) return rc;
+            } else if (kind == KIND_K3 && m[TM_PERM] && m[TM_WMASK] && m[TM_ORDER] && m[TM_NBR] && m[TM_NIN] == m[TM_NOUT] &&
+                       Cin % 32 == 0 && Cout % 32 == 0 && lidog_get_sparse_core() == 1) {
+                // output-stationary data gradient over the mirrored offsets of the map's sorted rows; what reached the
+                // input buffer earlier (the residual branch of a block) is added in its epilogue, as the reduction pass
+                // does.  The BatchNorm-backward sums of the producing layer then come from the stand-alone reduction
+                // (the operator path's kernel: the same bits).
+                const bool folds = op[TO_FOLD] && gs[in_b] != 0;
+                float *gx = target(in_b);
+                TRY(lidog_sconv_os(gout, P<const int32_t>(m[TM_NBR]), n_in, K, P<const int32_t>(m[TM_PERM]),
+                                   P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), Wt, 1, nullptr,
+                                   folds ? gp[in_b] : nullptr, Cout, Cin, gx, stream));
+                if (!wgrad_done)
+                    if (int rc = queue_wgrad()) return rc;
+                if (folds) {
+                    gp[in_b] = gx;
+                    gs[in_b] = 2;
+                } else if (int rc = commit(in_b, gx)) {
+                    return rc;
+                }
             } else {
                 float *T = (float *)sc.take(m[TM_P] * Cin * 4);
                 if (int rc = gemm(ctx, m, gout, n, g_out, Wt, nullptr, Cout, Cin, T, nullptr, stream)) return rc;
@@ -676,6 +721,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                     bwd_sums[po] = sums;
                     gp[in_b] = gx;
                     gs[in_b] = 2;
+                    if (g_timing && !ctx.dry) g_work[3] += 8.0 * (double)n_in * Cin;   // saved input + mask / addend
                 } else if (folds) {
                     // the residual branch's gradient of the block input enters the sum in the reduction's epilogue
                     TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, gp[in_b], gx, stream));
@@ -684,6 +730,10 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 } else {
                     TRY(lidog_sconv_reduce_rows(T, rp, rl, n_in, Cin, nullptr, nullptr, gx, stream));
                     if (int rc = commit(in_b, gx)) return rc;
+                }
+                if (g_timing && !ctx.dry) {
+                    g_work[2] += 1;
+                    g_work[3] += 4.0 * ((double)m[TM_P] + n_in) * Cin + 4.0 * ((double)m[TM_P] + n_in);
                 }
             }
         }
@@ -739,6 +789,16 @@ extern "C" int32_t lidog_trunk_fusions(int32_t mask) {
 // FLOPs, algorithmic bytes) in out[0..3], then forgets them.  Not thread-safe: one timing client per process.
 extern "C" int lidog_trunk_gemm_timing(int32_t on) {
     g_timing = on != 0;
+    return 0;
+}
+
+// [0] MFMA weight-gradient launches, [1] their algorithmic bytes, [2] per-row reduction launches, [3] their algorithmic
+// bytes, accumulated by the executor while lidog_trunk_gemm_timing is on; reading resets them
+extern "C" int lidog_trunk_work_read(double *out) {
+    for (int i = 0; i < 4; ++i) {
+        out[i] = g_work[i];
+        g_work[i] = 0;
+    }
     return 0;
 }
 

@@ -120,6 +120,28 @@ class KernelMap:
     pos_out = property(lambda self: self._pos_table("out"))
     pos_in = property(lambda self: self._pos_table("in"))
 
+    def sorted(self):
+        """(perm, wave_masks, tile_order) of lidog_kernel_map_sorted -- the rows sorted by neighbour mask, for the
+        output-stationary convolution (csrc/sconv_os.hip) -- or None where that kernel does not apply: only 3^3 maps
+        of a coordinate map onto itself (symmetric: one sorted order serves forward and data gradient), and only
+        sparse ones (LIDOG_SCONV_OS_DENSITY pairs per row at most, default 6: denser maps fill the two-pass path's
+        tiles better than they fill these; measured at tensor strides 1 / 2 vs 4 and up of the bench scans).
+        LIDOG_SCONV_OS=0 switches it off, =2 takes it for every symmetric 3^3 map."""
+        if "_sorted" not in self.__dict__:
+            self._sorted = None
+            ok = _SCONV_OS and self.K == 27 and self.n_in == self.n_out and self.nbr is not None and self.n_out > 0
+            if ok and (_SCONV_OS == 2 or self.P <= _SCONV_OS_DENSITY * self.n_out):
+                n, dev = self.n_out, self.nbr.device
+                pad = (n + 127) // 128 * 128
+                perm = torch.empty(pad, dtype=torch.int32, device=dev)
+                wmask = torch.empty(pad // 32, dtype=torch.int32, device=dev)
+                order = torch.empty(pad // 128, dtype=torch.int32, device=dev)
+                ws = torch.empty(_lib.load().lidog_kernel_map_sorted_ws(n), dtype=torch.uint8, device=dev)
+                call("lidog_kernel_map_sorted", ptr(self.nbr), n, self.K, ptr(self.k_off), ptr(perm), ptr(wmask),
+                     ptr(order), ptr(ws), ws.numel())
+                self._sorted = (perm, wmask, order)
+        return self._sorted
+
     def rows(self, side):
         """(row_ptr int32 [n+1], row_list int32 [P]) of the output ("out") or input ("in") rows: the pair positions
         of every row in ascending offset order -- what the reduction pass walks (include/lidog_amd.h:
@@ -150,6 +172,9 @@ class _IdentityMap:
 
 _SIDE_STREAMS = {}
 _EXP_KEPT = {}
+# output-stationary 3^3 convolution (KernelMap.sorted): 0 = off, 1 = sparse symmetric maps (default), 2 = every one
+_SCONV_OS = int(os.environ.get("LIDOG_SCONV_OS", "1"))
+_SCONV_OS_DENSITY = float(os.environ.get("LIDOG_SCONV_OS_DENSITY", "6.0"))
 
 
 # stream priorities of the helper streams (HIP: lower number = served first; the step itself runs on torch's current
@@ -537,6 +562,8 @@ class CoordinateManager:
         # the strided convolution's forward and the transposed convolution's data gradient, both over the coarse rows)
         if K == 27:
             self._own(*m.rows("out"), *m.rows("in"))
+            if m.sorted() is not None:
+                self._own(*m.sorted())
         elif K == 8:
             self._own(*m.rows("out"))
         return m
@@ -774,6 +801,13 @@ def _wgrad_items(m, Cin, Cout):
     return cache[chunk]
 
 
+def _os_rows(m, swap, Cin, Cout):
+    """the sorted rows of the map if this convolution takes the output-stationary kernel, else None"""
+    if swap or isinstance(m, _IdentityMap) or Cin % 32 or Cout % 32 or _lib.load().lidog_get_sparse_core() != 1:
+        return None
+    return m.sorted()
+
+
 class _SparseConvFn(torch.autograd.Function):
     """out = conv(x) over a rule book.  `single_out`: every output row has exactly one pair (transposed
     k2 s2) -> the GEMM scatters straight into `out`; `single_in`: every input row has exactly one pair
@@ -804,6 +838,29 @@ class _SparseConvFn(torch.autograd.Function):
             # the stem: straight from the neighbour table, no product rows (bit-identical to the two-pass path); the
             # BatchNorm statistics of its 32-channel output are then one small pass of their own
             call("lidog_sconv_cin1", ptr(x), ptr(m.nbr), ptr(W3), ptr(bias), n_out, K, Cout, ptr(out))
+        elif _os_rows(m, swap, Cin, Cout) is not None:
+            # sparse symmetric 3^3 map: output-stationary kernel, no product rows (bit-identical convolution; the
+            # statistics are summed per tile instead of per row block)
+            perm, wmask, order = _os_rows(m, swap, Cin, Cout)
+            dev = x.device
+            if stats is not None:
+                sums = stats.sums_out if stats.sums_out is not None else \
+                    torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
+                ws = torch.empty(_lib.load().lidog_sconv_os_stats_ws(n_out, Cout), dtype=torch.float64, device=dev)
+                if stats.sync:
+                    call("lidog_sconv_os_stats", ptr(x), ptr(m.nbr), n_out, K, ptr(perm), ptr(wmask), ptr(order), ptr(W3),
+                         ptr(bias), Cin, Cout, ptr(out), ptr(sums), ptr(ws), float(n_out), 0.0, 0.0, None, None, None,
+                         None)
+                else:
+                    stats.mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+                    stats.invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+                    call("lidog_sconv_os_stats", ptr(x), ptr(m.nbr), n_out, K, ptr(perm), ptr(wmask), ptr(order), ptr(W3),
+                         ptr(bias), Cin, Cout, ptr(out), ptr(sums), ptr(ws), float(n_out), stats.eps, stats.momentum,
+                         ptr(stats.mean), ptr(stats.invstd), ptr(stats.running_mean), ptr(stats.running_var))
+                stats.sums = sums
+            else:
+                call("lidog_sconv_os", ptr(x), ptr(m.nbr), n_out, K, ptr(perm), ptr(wmask), ptr(order), ptr(W3), 0,
+                     ptr(bias), None, Cin, Cout, ptr(out))
         else:
             T = torch.empty((m.P, Cout), dtype=torch.float32, device=x.device)
             _gemm(x, g_in, W3, None, m, Cin, Cout, T, None)
@@ -892,6 +949,15 @@ class _SparseConvFn(torch.autograd.Function):
                 _gemm(gout, None, Wt, None, m, Cout, Cin, gx, None)
             elif ctx.single_in:
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, gx, g_in)
+            elif _os_rows(m, swap, Cin, Cout) is not None:
+                # the data gradient over the mirrored offsets of the same sorted rows (csrc/sconv_os.hip); the residual
+                # branch's gradient is added in its epilogue, as the reduction pass does
+                perm, wmask, order = _os_rows(m, swap, Cin, Cout)
+                call("lidog_sconv_os", ptr(gout), ptr(m.nbr), n_in, K, ptr(perm), ptr(wmask), ptr(order), ptr(Wt), 1,
+                     None, ptr(gskip), Cout, Cin, ptr(gx))
+                gskip = None
+                if ctx.needs_input_grad[1] and behind:
+                    gW = queue_wgrad()
             else:
                 T = torch.empty((m.P, Cin), dtype=torch.float32, device=x.device)
                 _gemm(gout, g_out, Wt, None, m, Cout, Cin, T, None)

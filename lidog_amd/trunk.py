@@ -28,7 +28,7 @@ if "LIDOG_TRUNK_FUSIONS" in os.environ:     # A/B runs: bit mask of the executor
 
 KIND_K3, KIND_DOWN, KIND_UP, KIND_1X1, KIND_STEM = range(5)
 OP_CONVBN, OP_CAT, OP_CONV = range(3)
-TC_COLS, TM_COLS, TO_COLS, TB_COLS, REC_COLS = 20, 16, 8, 4, 4
+TC_COLS, TM_COLS, TO_COLS, TB_COLS, REC_COLS = 20, 20, 8, 4, 4
 (TC_KIND, TC_MAP, TC_CIN, TC_COUT, TC_K, TC_W, TC_WT, TC_GW, TC_BIAS, TC_GBIAS, TC_BNW, TC_BNB, TC_BNRM, TC_BNRV,
  TC_GBNW, TC_GBNB, TC_ITEMS, TC_NITEMS, TC_ITEMOFF) = range(19)
 # external buffers: the input features and the tensors the model hands back
@@ -317,8 +317,10 @@ def _build_tables(prog, x, run):
                 rp_o, rl_o = m.rows("out")
             if "in" in prog.rows_need[i]:
                 rp_i, rl_i = m.rows("in")
+            srt = m.sorted() or (None, None, None)   # sorted rows: the output-stationary 3^3 kernel applies (me.KernelMap.sorted)
             row = [m.K, m.n_in, m.n_out, m.P, _addr(m.pair_in), _addr(m.pair_out), _addr(rp_o), _addr(rl_o),
-                   _addr(rp_i), _addr(rl_i), _addr(m.tiles), m.n_tiles, _addr(m.nbr), 0]
+                   _addr(rp_i), _addr(rl_i), _addr(m.tiles), m.n_tiles, _addr(m.nbr), 0, _addr(srt[0]), _addr(srt[1]),
+                   _addr(srt[2])]
         if m.P == 0 or m.n_tiles == 0 or not m.tiles.is_contiguous():
             return None
         maps[i, :len(row)] = row

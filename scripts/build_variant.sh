@@ -1,15 +1,20 @@
 #!/bin/bash
-# scripts/build_variant.sh <name> <source.hip> <extra hipcc flags...>: liblidog_amd_<name>.so with ONE source rebuilt
-# under extra flags (kernel A/B runs: LIDOG_SO=lidog_amd/_C/liblidog_amd_<name>.so python bench.py)
+# Builds a variant of the library with extra compiler flags for ONE source file, for kernel A/B runs on the GPU box:
+#   scripts/build_variant.sh <name> <file.hip> -DFOO [-DBAR ...]   ->  lidog_amd/_C/variants/liblidog_<name>.so
+# (the other objects are the plain build's).  Run with LIDOG_SO=$PWD/lidog_amd/_C/variants/liblidog_<name>.so.
+# Experiment switches live in the sources only while an experiment is being measured; the shipped library is always the
+# plain build of lidog_amd/build.py.
 set -e
-name=$1; src=$2; shift 2
-C=lidog_amd/_C
-python -m lidog_amd.build > /dev/null
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off "$@" -c lidog_amd/csrc/$src -o $C/${src%.hip}_$name.o
-objs=$(ls $C/*.o | grep -v "_[a-z0-9]*\.o$" | grep -v "/${src%.hip}.o"; true)
+name=$1; file=$2; shift 2
+cd "$(dirname "$0")/.."
+python -c "from lidog_amd import build; build.build()" > /dev/null
+out=lidog_amd/_C/variants; mkdir -p $out
+obj=$out/${file%.hip}_$name.o
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -ffp-contract=off "$@" -c lidog_amd/csrc/$file -o $obj
 objs=""
-for o in coords sconv sconv_mfma bn bev conv2d conv2d_sparse data losses optim comm trunk hostprep; do
-  if [ "$o" = "${src%.hip}" ]; then objs="$objs $C/${o}_$name.o"; else objs="$objs $C/$o.o"; fi
+for f in lidog_amd/_C/*.o; do
+  [ "$(basename $f)" = "${file%.hip}.o" ] && objs="$objs $obj" || objs="$objs $f"
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $C/liblidog_amd_$name.so $objs -ldl
-echo $C/liblidog_amd_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/liblidog_$name.so $objs -ldl
+rm -f $obj
+echo $out/liblidog_$name.so

@@ -297,14 +297,18 @@ def test_two_rank_bench_keeps_replicas_identical():
     running statistics (the data-parallel invariant; bench.py checks it over the ranks)"""
     import json
     import subprocess
-    env = dict(os.environ, LIDOG_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29100 + os.getpid() % 800
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--min-seconds", "0.1", "--batch", "2"]
+    env = dict(os.environ, LIDOG_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LIDOG_PEER_ALLREDUCE="1")
+    # no launcher environment: `python bench.py --gpus 2` starts its two ranks itself (the driver's torch.distributed.run
+    # line, from a parent that never touches the GPU) and relays rank 0's line
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--min-seconds", "0.1", "--batch", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2+syncbn" and line["config"]["global_batch"] == 4
     assert line["config"]["trunk_path"] == "executor" and line["config"]["statistics_allreduce"] == "peer one-shot"
     assert line["replicas_identical"] == {"parameters": True, "syncbn_running_statistics": True}
+    assert line["rccl_ranks_seen"]["torch_process_group"] == 2 and line["config"]["peer_note"] == "on"
+    assert "peer_one_shot" in line["statistics_allreduce_us"] and "peer_error" not in line

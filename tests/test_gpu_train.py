@@ -222,7 +222,8 @@ def _dp_worker(rank, world, port, q, executor=True):
 
 
 def _dp_worker_body(rank, world, port, q, executor):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # LIDOG_PEER_ALLREDUCE=1: the statistics messages take the one-shot peer all-reduce (opt-in for the step)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIDOG_PEER_ALLREDUCE="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))

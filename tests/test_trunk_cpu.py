@@ -154,7 +154,7 @@ def test_tables_are_checked(prog):
     levels = [20000, 12000, 6000, 2500, 900]
     lv = np.array(levels, np.int64)
     maps, convs, conv_f = _tables(prog, levels)
-    maps[2, trunk.TM_COLS - 14] += 1          # n_in of the first 3^3 map no longer matches its buffers
+    maps[2, 2] += 1          # n_in of the first 3^3 map no longer matches its buffers
     ext = np.full(7, 4096, np.int64)
     rec, need = np.zeros(prog.n_rec, np.int64), np.zeros(2, np.int64)
     rc = L.lidog_trunk_forward(convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps),
