@@ -319,10 +319,17 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                         an1 = arow[4 * j + 6];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef OS_EXP_CHAIN   // timing experiment: one accumulator across the offsets (another rounding: NOT the reference's sums)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], acc[t], 0, 0, 0);
+#else
 #pragma unroll
                     for (int t = 0; t < NT; ++t) part[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], part[t], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) part[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], part[t], 0, 0, 0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 < OS_BK / 4) {
 #pragma unroll

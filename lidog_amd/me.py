@@ -123,14 +123,17 @@ class KernelMap:
     def sorted(self):
         """(perm, wave_masks, tile_order) of lidog_kernel_map_sorted -- the rows sorted by neighbour mask, for the
         output-stationary convolution (csrc/sconv_os.hip) -- or None where that kernel does not apply: only 3^3 maps
-        of a coordinate map onto itself (symmetric: one sorted order serves forward and data gradient), and only
-        sparse ones (LIDOG_SCONV_OS_DENSITY pairs per row at most, default 6: denser maps fill the two-pass path's
-        tiles better than they fill these; measured at tensor strides 1 / 2 vs 4 and up of the bench scans).
+        of a coordinate map onto itself (symmetric: one sorted order serves forward and data gradient), only sparse
+        ones (LIDOG_SCONV_OS_DENSITY pairs per row at most, default 6: denser maps fill the two-pass path's tiles
+        better than they fill these; measured at tensor strides 1 / 2 vs 4 and up of the bench scans) and only large
+        ones (LIDOG_SCONV_OS_MIN_TILES 128-row tiles, default 1500: a tile walks 5 to 27 offsets one after the other,
+        so a grid of a few hundred tiles ends on its longest ones -- 8 k-point scans ran 2.4 x slower with it).
         LIDOG_SCONV_OS=0 switches it off, =2 takes it for every symmetric 3^3 map."""
         if "_sorted" not in self.__dict__:
             self._sorted = None
             ok = _SCONV_OS and self.K == 27 and self.n_in == self.n_out and self.nbr is not None and self.n_out > 0
-            if ok and (_SCONV_OS == 2 or self.P <= _SCONV_OS_DENSITY * self.n_out):
+            if ok and (_SCONV_OS == 2 or (self.P <= _SCONV_OS_DENSITY * self.n_out and
+                                          self.n_out >= 128 * _SCONV_OS_MIN_TILES)):
                 n, dev = self.n_out, self.nbr.device
                 pad = (n + 127) // 128 * 128
                 perm = torch.empty(pad, dtype=torch.int32, device=dev)
@@ -175,6 +178,7 @@ _EXP_KEPT = {}
 # output-stationary 3^3 convolution (KernelMap.sorted): 0 = off, 1 = sparse symmetric maps (default), 2 = every one
 _SCONV_OS = int(os.environ.get("LIDOG_SCONV_OS", "1"))
 _SCONV_OS_DENSITY = float(os.environ.get("LIDOG_SCONV_OS_DENSITY", "6.0"))
+_SCONV_OS_MIN_TILES = int(os.environ.get("LIDOG_SCONV_OS_MIN_TILES", "1500"))
 
 
 # stream priorities of the helper streams (HIP: lower number = served first; the step itself runs on torch's current

@@ -115,8 +115,9 @@ def test_statistics_forms_and_bench_size_map():
     b = synth.make_batch(range(2), "kitti120k", "cuda")
     ME, cm = _setup(b["coords_int"].cpu())
     m = cm.kernel_map(1, 1, 3)
-    assert m.sorted() is not None          # sparse symmetric map: the product path takes the kernel
-    perm, wm, order = m.sorted()
+    # which maps the product path hands to this kernel: sparse (<= 6 pairs per row) and large (>= 1500 tiles) ones
+    assert (m.sorted() is not None) == (m.P <= ME._SCONV_OS_DENSITY * m.n_out and m.n_out >= 128 * ME._SCONV_OS_MIN_TILES)
+    perm, wm, order = _sorted(m)
     n, Cin, Cout = m.n_out, 96, 96
     g = torch.Generator().manual_seed(5)
     x = torch.randn(n, Cin, generator=g).cuda()
