@@ -421,23 +421,14 @@ int lidog_kernel_map_sorted(const int32_t *nbr, int64_t n, int32_t K, const int6
 int lidog_sconv_os(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
                    const uint32_t *wave_masks, const int32_t *tile_order, const float *W, int32_t reverse,
                    const float *bias, const float *addend, int32_t Cin, int32_t Cout, float *out, void *stream);
-/* the same with the reduction pass's statistics in the epilogue (one partial row per tile, finished in-kernel):
- * lidog_sconv_os_stats = forward + BatchNorm statistics of the result (arguments as lidog_sconv_reduce_rows_stats);
- * lidog_sconv_os_bwdstats = data gradient (+ addend) + the BatchNorm-backward sums of the layer whose output gradient it
- * completes (arguments as lidog_sconv_reduce_rows_bwdstats; G [n, Cg], Wt [K][Cg][Cx], gx [n, Cx]).
- * ws: lidog_sconv_os_stats_ws(n, C) doubles, C = width of the result. */
+/* lidog_sconv_os_stats: the forward form with the BatchNorm statistics of its result in the epilogue (one partial row
+ * per tile, finished in-kernel; arguments as lidog_sconv_reduce_rows_stats).  ws: lidog_sconv_os_stats_ws(n, Cout) doubles. */
 int64_t lidog_sconv_os_stats_ws(int64_t n, int32_t C);
 int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
                          const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias,
                          int32_t Cin, int32_t Cout, float *out, double *sums, double *ws, double count, float eps,
                          float momentum, float *mean, float *invstd, float *running_mean, float *running_var,
                          void *stream);
-int lidog_sconv_os_bwdstats(const float *G, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
-                            const uint32_t *wave_masks, const int32_t *tile_order, const float *Wt, const float *addend,
-                            int32_t Cg, int32_t Cx, float *gx, const float *pre, const float *relu_y,
-                            const uint32_t *relu_bits, const float *mean, const float *invstd, const float *relu_w,
-                            const float *relu_b, double *sums, double *ws, double count, float *dw, float *db,
-                            void *stream);
 
 /* ------------------------------------------------------------------ host-side tables of a kernel map (csrc/hostprep.hip)
  * Pure host code.  k_off_host [K+1]: the rule book's offsets (lidog_kernel_map_pairs' k_off copied to the host).

@@ -153,19 +153,102 @@ __device__ __forceinline__ void os_frag_load(const float *p, float (&f)[NT]) {
     }
 }
 
-// What the epilogue adds to the store of the rows (the jobs of the reduction pass's statistics forms, sconv.hip):
-//   mode 1  BatchNorm statistics of the result: per-channel (sum x, sum x^2) in fp64, one partial row per tile, added in
-//           a fixed order and finalised by the last workgroup to arrive (stats_tail.h)        = k_sconv_reduce_rows4_stats
-//   mode 2  the result is the complete gradient dy of the BatchNorm (+ReLU) output that `pre` is the input of:
-//           (sum dy', sum dy' xhat), dy' = dy masked by that layer's ReLU (mask from its bits, its saved output, or
-//           recomputed from pre with the forward pass's own expression)                        = ..._rows4_bwdstats
+// What the epilogue adds to the store of the rows: mode 1 = the BatchNorm statistics of the result, per-channel
+// (sum x, sum x^2) in fp64, one partial row per tile, added in a fixed order and finalised by the last workgroup to
+// arrive (stats_tail.h) -- the job of the reduction pass's statistics form (sconv.hip:k_sconv_reduce_rows4_stats).
+// (The backward-statistics form of that pass was built here too and measured: its epilogue -- the producer's saved input
+// and mask re-read per tile row -- costs what the stand-alone reduction costs, 0.047 vs 0.055 ms on a stride-1
+// 96-channel layer, and its sums are not the operator path's bits; the data gradient therefore stays plain + addend.)
 struct OsStats {
     int mode;
     StatsTail tail;
-    const float *pre, *relu_y;
-    const uint32_t *rbits;
-    const float *mean, *invstd, *rw, *rb;
 };
+
+// Epilogue: bias, addend, the rows' store through `s_row` (canonical row of every tile
+// row, -1 behind the end of the map) and the statistics of OsStats.  `red`: >= 4 * 2 * TN doubles of LDS the caller no
+// longer needs.  Called by all 256 threads of the workgroup.
+template <int NT>
+__device__ __forceinline__ void os_epilogue(f32x16 (&acc)[NT], const float (&bv)[NT], const int32_t *s_row, double *red,
+                                            int tile, int col0, int Cout, const float *__restrict__ addend,
+                                            float *__restrict__ out, const OsStats &st) {
+    constexpr int TN = 32 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // the last, redundant prefetch is drained once (vmcnt 0), see sconv_mfma.hip
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] += bv[t];
+    // per-lane statistics of this lane's 16 rows x NT columns (fp64), rows past the end of the map left out
+    double s0[NT], s1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s0[t] = s1[t] = 0.0;
+    // rows in two batches of eight: the addend loads of a batch are issued before the first use -- unconditionally, a row
+    // behind the end of the map reads row 0 and is masked afterwards (loads inside the per-row branch wait for memory
+    // sixteen times in a row)
+#pragma unroll
+    for (int eb = 0; eb < 16; eb += 8) {
+        int dst[8];
+        float adv[8][NT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = eb + u;
+            dst[u] = s_row[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
+            const size_t at = (size_t)(dst[u] < 0 ? 0 : dst[u]) * Cout + col0 + li * NT;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) adv[u][t] = addend ? addend[at + t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = eb + u;
+            const bool ok = dst[u] >= 0;
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[t][e] + adv[u][t];   // no addend: + 0
+            if (ok) {
+                float *o = out + (size_t)dst[u] * Cout + col0 + li * NT;
+                if constexpr (NT == 4) {
+                    *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if constexpr (NT == 2) {
+                    *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) o[t] = v[t];
+                }
+            }
+            if (st.mode == 1) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float x = ok ? v[t] : 0.f;
+                    s0[t] += (double)x;
+                    s1[t] += (double)x * (double)x;
+                }
+            }
+        }
+    }
+    if (st.mode != 0) {
+        // the tile's column sums: the two row halves of a wave (lanes l, l + 32), then the four waves in order
+        __syncthreads();   // every wave is done with the LDS that `red` aliases
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s0[t] += __shfl_xor(s0[t], 32);
+            s1[t] += __shfl_xor(s1[t], 32);
+            if (kh == 0) {
+                red[(wave * 2 + 0) * TN + li * NT + t] = s0[t];
+                red[(wave * 2 + 1) * TN + li * NT + t] = s1[t];
+            }
+        }
+        __syncthreads();
+        const int C2 = 2 * st.tail.C;
+        if (tid < 2 * TN) {
+            const int which = tid / TN, c = tid - which * TN;
+            const double v = ((red[(0 * 2 + which) * TN + c] + red[(1 * 2 + which) * TN + c]) +
+                              red[(2 * 2 + which) * TN + c]) + red[(3 * 2 + which) * TN + c];
+            lidog_store_sc1(st.tail.partial + (size_t)tile * C2 + which * st.tail.C + col0 + c, v);
+        }
+        lidog_stats_tail_rows(st.tail, tile, (int)gridDim.x, (int)gridDim.y);
+    }
+}
 
 // MFMA 32x32x2 lane maps as in sconv_mfma.hip: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 // D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5).  MFMA column tile t of a wave = columns {li * NT + t}.
@@ -190,11 +273,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
 
-#ifdef OS_EXP_NOSKIP
-    const uint32_t wm = 0xFFFFFFFFu;
-#else
     const uint32_t wm = wave_masks[tile * 4 + wave];
-#endif
     const uint32_t tm = wave_masks[tile * 4] | wave_masks[tile * 4 + 1] | wave_masks[tile * 4 + 2] | wave_masks[tile * 4 + 3];
     if (tid < OS_TM) s_row[tid] = perm[(int64_t)tile * OS_TM + tid];
     __syncthreads();
@@ -241,29 +320,18 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int src = s_nbr[k * OS_TM + (tid >> 3) + 32 * j];
-#ifdef OS_EXP_NOGATHER
-            src = (src < 0) ? -1 : (tile * OS_TM + (tid >> 3) + 32 * j) % (int)n;   // contiguous rows instead of neighbours
-#endif
             ok_nxt[j] = src >= 0;
             a_row[j] = A + (size_t)(src < 0 ? 0 : src) * Cin + q4;
         }
     };
     auto load_chunk = [&](int k, int kb) {
         const float *Bk = W + (size_t)(reverse ? K - 1 - k : k) * Cin * Cout + col0;
-#ifndef OS_EXP_NOA
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4 *>(a_row[j] + kb);
-#endif
-#ifndef OS_EXP_NOB
         OS_LOADB(0, rb0) OS_LOADB(1, rb1) OS_LOADB(2, rb2) OS_LOADB(3, rb3)
-#endif
     };
     auto next_offset = [&](uint32_t rem) { return reverse ? 31 - __builtin_clz(rem) : __builtin_ctz(rem); };
 
-#if defined(OS_EXP_NOA)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = make_float4(1.f, 2.f, 3.f, 4.f);
-#endif
     uint32_t rem = tm;
     if (rem != 0) {
         int k_cur = next_offset(rem);
@@ -319,17 +387,10 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                         an1 = arow[4 * j + 6];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#ifdef OS_EXP_CHAIN   // timing experiment: one accumulator across the offsets (another rounding: NOT the reference's sums)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], acc[t], 0, 0, 0);
-#else
 #pragma unroll
                     for (int t = 0; t < NT; ++t) part[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], part[t], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) part[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], part[t], 0, 0, 0);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 < OS_BK / 4) {
 #pragma unroll
@@ -341,7 +402,6 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                         a1 = an1;
                     }
                 }
-#ifndef OS_EXP_NOADD
                 if (last_of_offset) {   // the offset's product rows are complete: the reduction pass's addition
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
@@ -351,7 +411,6 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                             part[t][e] = 0.f;
                         }
                 }
-#endif
             }
             if (!more) break;
             if (last_of_offset) {
@@ -362,105 +421,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
             kb_cur = kb_nxt;
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // the last, redundant prefetch is drained once (vmcnt 0), see sconv_mfma.hip
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] += bv[t];
-    // per-lane statistics of this lane's 16 rows x NT columns (fp64), rows past the end of the map left out
-    double s0[NT], s1[NT];
-    float bn_m[NT], bn_is[NT], bn_w[NT], bn_b[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        s0[t] = s1[t] = 0.0;
-        bn_m[t] = 0.f; bn_is[t] = 1.f; bn_w[t] = 0.f; bn_b[t] = 1.f;
-    }
-    const bool from_x = st.mode == 2 && st.relu_y == nullptr && st.rw != nullptr;
-    const bool has_relu = st.mode == 2 && (st.relu_y != nullptr || from_x || st.rbits != nullptr);
-    if (st.mode == 2) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            bn_m[t] = st.mean[col0 + li * NT + t];
-            bn_is[t] = st.invstd[col0 + li * NT + t];
-            if (from_x) {
-                bn_w[t] = st.rw[col0 + li * NT + t];
-                bn_b[t] = st.rb[col0 + li * NT + t];
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const int dst = s_row[r];
-        if (dst >= 0) {
-            const size_t at = (size_t)dst * Cout + col0 + li * NT;
-            float *o = out + at;
-            float v[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = acc[t][e];
-            if (addend) {
-                const float *ad = addend + at;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] += ad[t];
-            }
-            if constexpr (NT == 4) {
-                *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if constexpr (NT == 2) {
-                *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) o[t] = v[t];
-            }
-            if (st.mode == 1) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    s0[t] += (double)v[t];
-                    s1[t] += (double)v[t] * (double)v[t];
-                }
-            } else if (st.mode == 2) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float x = st.pre[at + t];
-                    float y = 1.f;
-                    if (st.rbits) {
-                        const size_t el = at + t;                  // bit (el & 3) of nibble ((el >> 2) & 7) of word el >> 5
-                        y = (float)((st.rbits[el >> 5] >> (4 * (int)((el >> 2) & 7) + (int)(el & 3))) & 1u);
-                    } else if (st.relu_y) {
-                        y = st.relu_y[at + t];
-                    } else if (from_x) {   // the forward pass's pre-activation, bit for bit (bn.hip:k_bn_apply4)
-                        y = (x - bn_m[t]) * bn_is[t] * bn_w[t] + bn_b[t];
-                    }
-                    const float g = (has_relu && !(y > 0.f)) ? 0.f : v[t];   // = bn.hip:red_terms<1>
-                    const float xh = (x - bn_m[t]) * bn_is[t];
-                    s0[t] += (double)g;
-                    s1[t] += (double)g * (double)xh;
-                }
-            }
-        }
-    }
-    if (st.mode != 0) {
-        // the tile's column sums: the two row halves of a wave (lanes l, l + 32), then the four waves in order
-        __syncthreads();   // As is free now: it carries the waves' sums
-        double *red = reinterpret_cast<double *>(As);   // [4 waves][2][TN]
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            s0[t] += __shfl_xor(s0[t], 32);
-            s1[t] += __shfl_xor(s1[t], 32);
-            if (kh == 0) {
-                red[(wave * 2 + 0) * TN + li * NT + t] = s0[t];
-                red[(wave * 2 + 1) * TN + li * NT + t] = s1[t];
-            }
-        }
-        __syncthreads();
-        const int C2 = 2 * st.tail.C;
-        if (tid < 2 * TN) {
-            const int which = tid / TN, c = tid - which * TN;
-            const double v = ((red[(0 * 2 + which) * TN + c] + red[(1 * 2 + which) * TN + c]) +
-                              red[(2 * 2 + which) * TN + c]) + red[(3 * 2 + which) * TN + c];
-            lidog_store_sc1(st.tail.partial + (size_t)tile * C2 + which * st.tail.C + col0 + c, v);
-        }
-        lidog_stats_tail_rows(st.tail, tile, (int)gridDim.x, (int)gridDim.y);
-    }
+    os_epilogue<NT>(acc, bv, s_row, reinterpret_cast<double *>(As), tile, col0, Cout, addend, out, st);
 }
 
 static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const int32_t *perm,
@@ -538,34 +499,6 @@ extern "C" int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t 
     BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
     if (lidog_stats_tail_make(&stats.tail, ws, sums, count, Cout, fin, st)) return 1;
     int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats, st);
-    if (rc) return rc;
-    return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);
-}
-
-// Data gradient of the convolution over its (symmetric) map + the BatchNorm-backward statistics of the layer that
-// produced the rows it completes (= lidog_sconv_gemm with the transposed kernels + lidog_sconv_reduce_rows_bwdstats).
-// G [n, Cg]: gradient of the convolution's output; Wt [K][Cg][Cx]; gx [n, Cx] = result (+ addend); pre / relu_* /
-// mean / invstd / sums / dw / db: the producer's, as lidog_sconv_reduce_rows_bwdstats.
-extern "C" int lidog_sconv_os_bwdstats(const float *G, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
-                                       const uint32_t *wave_masks, const int32_t *tile_order, const float *Wt,
-                                       const float *addend, int32_t Cg, int32_t Cx, float *gx, const float *pre,
-                                       const float *relu_y, const uint32_t *relu_bits, const float *mean,
-                                       const float *invstd, const float *relu_w, const float *relu_b, double *sums,
-                                       double *ws, double count, float *dw, float *db, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    LIDOG_REQUIRE(pre && mean && invstd && sums && ws, "sconv_os_bwdstats: null argument");
-    LIDOG_REQUIRE((relu_w == nullptr) == (relu_b == nullptr) &&
-                      (relu_y != nullptr) + (relu_w != nullptr) + (relu_bits != nullptr) <= 1,
-                  "sconv_os_bwdstats: pass at most one of relu_y, relu_bits, (relu_w, relu_b)");
-    if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * Cx + 1), st) == hipSuccess ? 0 : 1;
-    LIDOG_REQUIRE(os_pad(n) / OS_TM <= (int64_t)STATS_MAX_GROUPS * STATS_GROUP, "sconv_os_bwdstats: too many tiles");
-    OsStats stats = {};
-    stats.mode = 2;
-    stats.pre = pre; stats.relu_y = relu_y; stats.rbits = relu_bits;
-    stats.mean = mean; stats.invstd = invstd; stats.rw = relu_w; stats.rb = relu_b;
-    BnFinish fin = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dw, db};
-    if (lidog_stats_tail_make(&stats.tail, ws, sums, count, Cx, fin, st)) return 1;
-    int rc = os_launch(G, nbr, n, K, perm, wave_masks, tile_order, Wt, 1, nullptr, addend, Cg, Cx, gx, stats, st);
     if (rc) return rc;
     return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);
 }

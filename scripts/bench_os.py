@@ -97,32 +97,5 @@ for s, Cin, Cout in [(1, 96, 96), (2, 32, 32), (1, 128, 96)]:
     assert torch.equal(o1, o2)
     e1 = ((su1[:-1] - ref).abs() / ref.abs().clamp_min(1e-3)).max().item(); e2 = ((su2[:-1] - ref).abs() / ref.abs().clamp_min(1e-3)).max().item()
     assert e2 < 1e-9 and su2[-1].item() == n and torch.allclose(me1, me2, rtol=1e-6, atol=1e-7) and torch.allclose(is1, is2, rtol=1e-6), (e1, e2)
-    # backward statistics: producer = BatchNorm + ReLU without residual (mask from x), with a bit mask, and none
-    g = torch.randn(n, Cout, device="cuda"); Wt = W.transpose(1, 2).contiguous(); T2 = torch.empty(m.P, Cin, device="cuda")
-    pre = torch.randn(n, Cin, device="cuda"); mean = pre.mean(0); invstd = 1.0 / (pre.var(0, unbiased=False) + 1e-5).sqrt()
-    bw = torch.rand(Cin, device="cuda") + 0.5; bb = torch.randn(Cin, device="cuda") * 0.1; ad = torch.randn(n, Cin, device="cuda")
-    y = torch.empty(n, Cin, device="cuda"); bits = torch.empty(L.lidog_relu_bits_words(n, Cin), dtype=torch.int32, device="cuda")
-    call("lidog_bn_apply_bits", ptr(pre), n, Cin, 1, ptr(mean), ptr(invstd), ptr(bw), ptr(bb), ptr(ad), 1, ptr(y), ptr(bits))
-    rpi, rli = m.rows("in")
-    for name, kw in (("mask from x", dict(rw=bw, rb=bb)), ("bit mask", dict(bits=bits)), ("saved output", dict(ry=y)), ("no relu", dict())):
-        ry, rbits, rw, rb = kw.get("ry"), kw.get("bits"), kw.get("rw"), kw.get("rb")
-        g1 = torch.empty(n, Cin, device="cuda"); g2 = torch.empty_like(g1)
-        sb1 = torch.empty(2 * Cin + 1, dtype=torch.float64, device="cuda"); sb2 = torch.empty_like(sb1)
-        wb1 = torch.empty(L.lidog_bn_reduce_ws(Cin, 1), dtype=torch.float64, device="cuda")
-        wb2 = torch.empty(L.lidog_sconv_os_stats_ws(n, Cin), dtype=torch.float64, device="cuda")
-        dw1 = torch.empty(Cin, device="cuda"); db1 = torch.empty(Cin, device="cuda"); dw2 = torch.empty(Cin, device="cuda"); db2 = torch.empty(Cin, device="cuda")
-        def bwd_two():
-            ME._gemm(g, m.pair_out, Wt, None, m, Cout, Cin, T2, None)
-            call("lidog_sconv_reduce_rows_bwdstats", ptr(T2), ptr(rpi), ptr(rli), n, Cin, ptr(ad), ptr(g1), ptr(pre), ptr(ry), ptr(rbits),
-                 ptr(mean), ptr(invstd), ptr(rw), ptr(rb), ptr(sb1), ptr(wb1), float(n), ptr(dw1), ptr(db1))
-        def bwd_os():
-            call("lidog_sconv_os_bwdstats", ptr(g), ptr(m.nbr), n, m.K, ptr(perm), ptr(wm), ptr(order), ptr(Wt), ptr(ad), Cout, Cin, ptr(g2),
-                 ptr(pre), ptr(ry), ptr(rbits), ptr(mean), ptr(invstd), ptr(rw), ptr(rb), ptr(sb2), ptr(wb2), float(n), ptr(dw2), ptr(db2))
-        tb1, tb2 = timeit(bwd_two), timeit(bwd_os)
-        assert torch.equal(g1, g2), name
-        rel = ((sb1[:-1] - sb2[:-1]).abs() / sb1[:-1].abs().clamp_min(1e-2)).max().item()
-        assert rel < 1e-9 and sb2[-1].item() == n and torch.allclose(dw1, dw2, rtol=1e-5, atol=1e-5) and torch.allclose(db1, db2, rtol=1e-5, atol=1e-5), (name, rel)
-        if name == "mask from x":
-            print("s%d %3d->%3d  fwd+stats two-pass %.3f os %.3f (%.2fx)   dgrad+bwdstats two-pass %.3f os %.3f (%.2fx)" % (
-                s, Cin, Cout, t1, t2, t1 / t2, tb1, tb2, tb1 / tb2))
+    print("s%d %3d->%3d  fwd+stats two-pass %.3f os %.3f (%.2fx)" % (s, Cin, Cout, t1, t2, t1 / t2))
 print("ok")
