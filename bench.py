@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak = vector fp32 peak (MI355X_MICROARCH.md, Matrix cores)
 # scripts/profile_round.sh <tag> writes profiles/<tag>_pmc_traffic_sconv_gemm_mfma.json (FETCH_SIZE / WRITE_SIZE passes)
-PMC_TRAFFIC_TAG = "r03_c"
+PMC_TRAFFIC_TAG = "r04_a"
 PMC_TRAFFIC_FILE = f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_gemm_mfma.json"
 
 
@@ -535,8 +535,8 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": tfl, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tfl / FP32_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_source": f"profiles/{PMC_TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                                 f"over the {PMC_TRAFFIC_TAG} build (the gathered GEMM is unchanged "
-                                                 "since), not collected by this run" if traffic is not None else None,
+                                                 f"over the {PMC_TRAFFIC_TAG} build (scripts/profile_round.sh), "
+                                                 "not collected by this run" if traffic is not None else None,
                                "kernel": "k_sconv_gemm_mfma (gathered GEMM of the sparse convolutions, f32 MFMA)",
                                "algorithmic_flops_per_launch": s["flops"] / s["launches"],
                                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
@@ -568,15 +568,17 @@ def main():
             # PMC traffic of the other two HBM-heavy families of the sparse stack, same passes, same build tag
             import ctypes
             from lidog_amd import _lib as _L2
-            wk = (ctypes.c_double * 4)()
+            wk = (ctypes.c_double * 6)()
             _L2.load().lidog_trunk_work_read(wk)   # algorithmic bytes of the executor's weight-gradient / reduction launches
             alg = {"k_sconv_gemm_mfma": s["bytes"] / s["launches"],
                    "k_sconv_wgrad_mfma": wk[1] / wk[0] if wk[0] else None,
-                   "k_sconv_reduce_rows4": wk[3] / wk[2] if wk[2] else None}
+                   "k_sconv_reduce_rows4": wk[3] / wk[2] if wk[2] else None,
+                   "k_sconv_os_mfma": wk[5] / wk[4] if wk[4] else None}
             ratios = {}
             for fam, fn in (("k_sconv_gemm_mfma", PMC_TRAFFIC_FILE),
                             ("k_sconv_wgrad_mfma", f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_wgrad_mfma.json"),
-                            ("k_sconv_reduce_rows4", f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_reduce_rows4.json")):
+                            ("k_sconv_reduce_rows4", f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_reduce_rows4.json"),
+                            ("k_sconv_os_mfma", f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_os_mfma.json")):
                 f = os.path.join(REPO, "profiles", fn)
                 if os.path.exists(f) and args.config == "kitti120k" and args.batch == 4 and alg[fam]:
                     d = json.load(open(f))

@@ -518,8 +518,9 @@ int32_t lidog_trunk_fusions(int32_t mask);
 int lidog_trunk_gemm_timing(int32_t on);
 int lidog_trunk_gemm_timing_read(double *out /*[4]*/);
 /* algorithmic bytes of the executor's MFMA weight-gradient and per-row reduction launches while the timing is on:
- * out[0] launches / out[1] bytes (weight gradient), out[2] / out[3] (reduction); reading resets the counters */
-int lidog_trunk_work_read(double *out);
+ * out[0] launches / out[1] bytes (weight gradient), out[2] / out[3] (reduction), out[4] / out[5] (output-stationary
+ * convolution); reading resets the counters */
+int lidog_trunk_work_read(double *out /*[6]*/);
 
 #ifdef __cplusplus
 }

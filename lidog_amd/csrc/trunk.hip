@@ -215,7 +215,7 @@ bool g_timing = false;
 // them against the PMC traffic of the same families): [0] MFMA weight-gradient launches, [1] their bytes
 // 4 P (Cin + Cout) + 4 K Cin Cout (1 + 2 slabs / K), [2] per-row reduction launches, [3] their bytes
 // 4 (P + N) C + 4 (P + N) (+ 8 N C for the saved input and mask / addend the backward-statistics form also reads)
-double g_work[4] = {0, 0, 0, 0};
+double g_work[6] = {0, 0, 0, 0, 0, 0};   // [4] output-stationary launches, [5] their bytes 4 n (Cin + Cout) + 4 K Cin Cout + 4 K n
 std::vector<GemmRec> g_recs;
 std::vector<hipEvent_t> g_spare;
 
@@ -355,6 +355,10 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                                      P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, bias, Cin, Cout,
                                      pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
             stats_done = true;
+            if (g_timing && !ctx.dry) {
+                g_work[4] += 1;
+                g_work[5] += 4.0 * n * (Cin + Cout) + 4.0 * K * Cin * Cout + 4.0 * K * n;
+            }
         } else if (os) {
             TRY(lidog_sconv_os(x, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
                                P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, 0, bias, nullptr, Cin,
@@ -676,6 +680,10 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 TRY(lidog_sconv_os(gout, P<const int32_t>(m[TM_NBR]), n_in, K, P<const int32_t>(m[TM_PERM]),
                                    P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), Wt, 1, nullptr,
                                    folds ? gp[in_b] : nullptr, Cout, Cin, gx, stream));
+                if (g_timing && !ctx.dry) {
+                    g_work[4] += 1;
+                    g_work[5] += 4.0 * n_in * (Cin + Cout + (folds ? Cin : 0)) + 4.0 * K * Cin * Cout + 4.0 * K * n_in;
+                }
                 if (!wgrad_done)
                     if (int rc = queue_wgrad()) return rc;
                 if (folds) {
@@ -793,9 +801,10 @@ extern "C" int lidog_trunk_gemm_timing(int32_t on) {
 }
 
 // [0] MFMA weight-gradient launches, [1] their algorithmic bytes, [2] per-row reduction launches, [3] their algorithmic
-// bytes, accumulated by the executor while lidog_trunk_gemm_timing is on; reading resets them
+// bytes, [4] output-stationary convolution launches, [5] theirs, accumulated by the executor while
+// lidog_trunk_gemm_timing is on; reading resets them
 extern "C" int lidog_trunk_work_read(double *out) {
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
         out[i] = g_work[i];
         g_work[i] = 0;
     }

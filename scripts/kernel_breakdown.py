@@ -6,10 +6,11 @@ import collections, sqlite3, sys
 db, steps = sys.argv[1], int(sys.argv[2])
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, stream_id from kernels order by start").fetchall()
-CATS = [("gathered GEMM (sconv fwd/dgrad)", ("k_sconv_gemm", "k_sconv_cin1<")), ("sparse wgrad", ("k_sconv_wgrad", "k_items_sum")),
+CATS = [("gathered GEMM (sconv fwd/dgrad)", ("k_sconv_gemm", "k_sconv_cin1<")),
+        ("output-stationary 3^3 convolution", ("k_sconv_os",)), ("sparse wgrad", ("k_sconv_wgrad", "k_items_sum")),
         ("per-row reduction", ("k_sconv_reduce",)), ("conv2d (BEV head)", ("k_conv_", "k_pw_", "k_repack", "k_sum_splits", "k_sum_group", "k_support", "k_tile_lists", "k_group_lists")),
         ("BatchNorm / ReLU / add", ("k_colreduce", "k_sums_", "k_bn_", "k_partials", "k_stats_finish", "k_relu", "k_add")),
-        ("coordinate + kernel maps", ("k_kernel_map", "k_pairs", "k_insert", "k_first_row", "k_stride", "scan_", "k_compact")),
+        ("coordinate + kernel maps", ("k_kernel_map", "k_pairs", "k_insert", "k_first_row", "k_stride", "scan_", "k_compact", "k_os_", "k_rows_", "k_bitmap", "DeviceRadixSort", "radix_sort", "rocprim")),
         ("BEV projection", ("k_bev",)), ("losses", ("k_dice",)), ("Adam", ("k_adam",)), ("weight transpose", ("k_transpose",))]
 agg = collections.OrderedDict((n, [0, 0.0]) for n, _ in CATS)
 agg["torch / runtime (copies, fills, cat, add)"] = [0, 0.0]

@@ -32,7 +32,7 @@ if [[ $what == *pmc* ]]; then
   d=gpurun_out/pmc_${tag}_SQ; rm -rf $d
   STEPS=2 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $d -o p -- python3 scripts/prof_train.py > gpurun_out/pmc_${tag}_SQ.log 2>&1 || \
   STEPS=2 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $d -o p -- python3 scripts/prof_train.py > gpurun_out/pmc_${tag}_SQ.log 2>&1
-  for k in k_sconv_gemm_mfma k_sconv_wgrad_mfma k_conv_s2 k_sconv_reduce_rows4; do
+  for k in k_sconv_gemm_mfma k_sconv_os_mfma k_sconv_wgrad_mfma k_conv_s2 k_sconv_reduce_rows4; do
     python3 scripts/pmc_traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE $k > $out/${tag}_pmc_traffic_${k#k_}.json 2>/dev/null || rm -f $out/${tag}_pmc_traffic_${k#k_}.json
   done
   python3 scripts/pmc_sq.py gpurun_out/pmc_${tag}_SQ > $out/${tag}_pmc_sq_all_kernels.txt

@@ -35,11 +35,15 @@ def _sha_coords(t):
     return hashlib.sha1(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
 
 
-def test_minkunet34bev_matches_reference_golden():
+@pytest.mark.parametrize("os_mode", [1, 2], ids=["two_pass_convolutions", "output_stationary_convolutions"])
+def test_minkunet34bev_matches_reference_golden(os_mode, monkeypatch):
     import lidog_amd
     import lidog_amd.me as ME
     from lidog_amd.losses import SoftDICELoss, DICELoss
     from lidog_amd.trainer import FlatAdam
+    # os_mode 2: every 3^3 same-stride convolution through the output-stationary kernel (csrc/sconv_os.hip), which by
+    # default only large sparse maps take; same bars against the same golden run of the reference's classes
+    monkeypatch.setattr(ME, "_SCONV_OS", os_mode)
     g5 = np.load(f"{GOLDEN}/g5_minkunet34bev.npz")
     C = torch.from_numpy(g5["coords"]).cuda()
     labels = torch.from_numpy(g5["labels"]).cuda()

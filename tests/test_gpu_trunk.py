@@ -45,15 +45,18 @@ def _assert_same(a, b, what):
             assert torch.equal(a[k], b[k]), f"{what} {k}: max |diff| {(a[k] - b[k]).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("fusions", [3, 1, 0], ids=["fused", "bwdstats_only", "plain_sequence"])
+@pytest.mark.parametrize("fusions,os_mode", [(3, 1), (1, 1), (0, 1), (3, 2), (0, 2)],
+                         ids=["fused", "bwdstats_only", "plain_sequence", "fused_output_stationary", "plain_output_stationary"])
 @pytest.mark.parametrize("overlap", [True, False])
-def test_executor_step_is_bit_identical_to_the_operator_path(overlap, fusions):
+def test_executor_step_is_bit_identical_to_the_operator_path(overlap, fusions, os_mode, monkeypatch):
     """3 optimiser steps of the LiDOG step (Adam on flat buffers), executor on vs off; with the executor's fusions
     (BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction, ReLU masks of the residual
-    layers as bits) and without them"""
+    layers as bits) and without them; os_mode 2: every symmetric 3^3 map takes the output-stationary convolution
+    (csrc/sconv_os.hip; by default only maps of >= 1500 tiles do, which these scenes are not)"""
     from lidog_amd import me as ME, trunk
     from lidog_amd.trainer import LiDOGStep
     from lidog_amd.optim import make_optimizer
+    monkeypatch.setattr(ME, "_SCONV_OS", os_mode)
     ME.set_backward_overlap(overlap)
     before = trunk.set_fusions(fusions)
     try:
