@@ -172,11 +172,15 @@ int check_tables(const Ctx &ctx, bool grads) {
                               "trunk: op %d: residual of another shape", o);
         }
         switch (kind) {
-            case KIND_K3:
-                LIDOG_REQUIRE(m[TM_PAIR_IN] && m[TM_PAIR_OUT] && m[TM_RP_OUT] && m[TM_RL_OUT] && m[TM_RP_IN] &&
-                                  m[TM_RL_IN] && c[TC_CIN] % 4 == 0,
+            case KIND_K3: {
+                // sorted rows (output-stationary kernel) stand in for the per-row lists of the reduction pass
+                const bool os = m[TM_PERM] && m[TM_WMASK] && m[TM_ORDER] && m[TM_NBR] && m[TM_NIN] == m[TM_NOUT] &&
+                                c[TC_CIN] % 32 == 0 && c[TC_COUT] % 32 == 0 && lidog_get_sparse_core() == 1;
+                LIDOG_REQUIRE(m[TM_PAIR_IN] && m[TM_PAIR_OUT] && c[TC_CIN] % 4 == 0 &&
+                                  (os || (m[TM_RP_OUT] && m[TM_RL_OUT] && m[TM_RP_IN] && m[TM_RL_IN])),
                               "trunk: op %d: 3^3 map without pair or row lists", o);
                 break;
+            }
             case KIND_DOWN:
             case KIND_UP:
                 LIDOG_REQUIRE(m[TM_PAIR_IN] && m[TM_PAIR_OUT] && m[TM_RP_OUT] && m[TM_RL_OUT] && c[TC_CIN] % 4 == 0,

@@ -179,6 +179,7 @@ _EXP_KEPT = {}
 _SCONV_OS = int(os.environ.get("LIDOG_SCONV_OS", "1"))
 _SCONV_OS_DENSITY = float(os.environ.get("LIDOG_SCONV_OS_DENSITY", "6.0"))
 _SCONV_OS_MIN_TILES = int(os.environ.get("LIDOG_SCONV_OS_MIN_TILES", "1500"))
+_OS_HINT = {}     # kernel-map key -> the map of the previous batch took the output-stationary kernel
 
 
 # stream priorities of the helper streams (HIP: lower number = served first; the step itself runs on torch's current
@@ -548,7 +549,10 @@ class CoordinateManager:
         pair_out = torch.empty(n_out * K, dtype=torch.int32, device=self.device)
         # position tables: what the per-row lists are built from (3^3 and 2^3 maps) and what the dense-table reduction
         # of odd channel counts walks; a 5^3 map (the stem: straight from the neighbour table) never needs them
-        by_row = K <= 27
+        # ... nor does a map whose rows were sorted for the output-stationary kernel the last time a batch went through
+        # this network (_OS_HINT: the decision needs the pair count, which this batch does not have yet; if it comes out
+        # differently the tables are rebuilt from the pair lists on first use, KernelMap._pos_table)
+        by_row = K <= 27 and not (K == 27 and s_in == s_out and _OS_HINT.get(key, False))
         pos_out = torch.empty((K, n_out), dtype=torch.int32, device=self.device) if by_row else None
         pos_in = torch.empty((K, n_in), dtype=torch.int32, device=self.device) if by_row else None
         nbp = (n_out + 1023) // 1024
@@ -565,9 +569,13 @@ class CoordinateManager:
         # per-row lists for the reduction passes that will use this map (3^3: forward and data gradient; 2^3 stride 2:
         # the strided convolution's forward and the transposed convolution's data gradient, both over the coarse rows)
         if K == 27:
-            self._own(*m.rows("out"), *m.rows("in"))
-            if m.sorted() is not None:
-                self._own(*m.sorted())
+            srt = m.sorted()
+            if key is not None:
+                _OS_HINT[key] = srt is not None
+            if srt is not None:
+                self._own(*srt)      # nobody walks this map by row: no per-row lists (built on first use if asked for)
+            else:
+                self._own(*m.rows("out"), *m.rows("in"))
         elif K == 8:
             self._own(*m.rows("out"))
         return m

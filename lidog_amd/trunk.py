@@ -168,9 +168,14 @@ class Program:
         self.bns = [bnm for _, bnm, _, _, _ in self.convs if bnm is not None]
         # which row lists every map needs
         self.rows_need = [set() for _ in self.map_keys]
-        for (_, _, kind, _, _), mi in zip(self.convs, self.conv_map):
+        # os_ok[mi]: every 3^3 convolution on the map has channel counts the output-stationary kernel takes; where the
+        # map's rows are sorted for it (me.KernelMap.sorted) nobody walks its per-row lists and they are not built
+        self.os_ok = [True for _ in self.map_keys]
+        for (cv, _, kind, _, _), mi in zip(self.convs, self.conv_map):
             if kind == KIND_K3:
                 self.rows_need[mi] |= {"out", "in"}
+                if cv.in_channels % 32 or cv.out_channels % 32:
+                    self.os_ok[mi] = False
             elif kind in (KIND_DOWN, KIND_UP):
                 self.rows_need[mi].add("out")
         self.n_rec = len(ops) * REC_COLS + len(bufs)
@@ -313,11 +318,12 @@ def _build_tables(prog, x, run):
         else:
             m = cm.kernel_map(*key)
             rp_o = rl_o = rp_i = rl_i = None
-            if "out" in prog.rows_need[i]:
-                rp_o, rl_o = m.rows("out")
-            if "in" in prog.rows_need[i]:
-                rp_i, rl_i = m.rows("in")
             srt = m.sorted() or (None, None, None)   # sorted rows: the output-stationary 3^3 kernel applies (me.KernelMap.sorted)
+            by_rows = srt[0] is None or not prog.os_ok[i] or _lib.load().lidog_get_sparse_core() != 1
+            if "out" in prog.rows_need[i] and by_rows:
+                rp_o, rl_o = m.rows("out")
+            if "in" in prog.rows_need[i] and by_rows:
+                rp_i, rl_i = m.rows("in")
             row = [m.K, m.n_in, m.n_out, m.P, _addr(m.pair_in), _addr(m.pair_out), _addr(rp_o), _addr(rl_o),
                    _addr(rp_i), _addr(rl_i), _addr(m.tiles), m.n_tiles, _addr(m.nbr), 0, _addr(srt[0]), _addr(srt[1]),
                    _addr(srt[2])]
