@@ -18,7 +18,8 @@ if DP:                                          # LIDOG_BENCH_SINGLE_RANK_DP=1)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     ME.MinkowskiSyncBatchNorm.single_rank = GradientBuckets.single_rank = True
-if cfg == "kitti120k":
+BS = int(os.environ.get("BS", 4))               # scans per step (config 5, highres524k: BS=1)
+if cfg in ("kitti120k", "highres524k"):
     model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=50.0).cuda().train()
     if DP:
         model = setup_data_parallel(model)
@@ -26,7 +27,7 @@ if cfg == "kitti120k":
 else:
     model = lidog_amd.MinkUNet34(1, 7, 3).cuda().train()
     step = SourceStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4))
-batches = [synth.make_batch(range(4 * i, 4 * i + 4), cfg, "cuda") for i in range(2)]
+batches = [synth.make_batch(range(BS * i, BS * i + BS), cfg, "cuda") for i in range(2)]
 READY = torch.cuda.Event(); READY.record(); torch.cuda.synchronize()
 n = int(os.environ.get("STEPS", 5))
 import contextlib

@@ -2,7 +2,8 @@
 # One round's profile set on the GPU box:  bash scripts/profile_round.sh <tag> [what...]
 #   what: trace (kernel trace, two-stream + one-stream), pmc (FETCH_SIZE / WRITE_SIZE / SQ busy passes)   default: both
 # Writes summaries straight into profiles/<tag>_* copies under gpurun_out/profiles/ (gpurun merges gpurun_out back);
-# copy the ones to keep into profiles/.  The profiled command is scripts/prof_train.py (training steps only), the
+# copy the ones to keep into profiles/.  CONFIG / BS in the environment select another workload (config 5:
+# CONFIG=highres524k BS=1).  The profiled command is scripts/prof_train.py (training steps only), the
 # program directly after `--` as gpurun requires; counters in their own passes (never with a trace domain).
 set -e
 tag=$1; shift
