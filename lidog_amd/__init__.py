@@ -14,7 +14,35 @@ import os as _os
 # must not share a hardware queue: the runtime's default is 4 queues for all streams of a process, and at 8 the
 # data-parallel step still serialised (67.7 vs 50.7 ms per step at 16); only effective when set before the HIP runtime
 # starts
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_HW_QUEUES_WANTED = 16
+
+
+def _hardware_queues():
+    """GPU_MAX_HW_QUEUES is read once, when the HIP runtime starts.  Set it if nobody has; if the runtime is already up
+    (the host application touched the GPU before importing this package) with fewer queues than the streams of a step
+    need, say so: nothing fails, the step just serialises (measured: data-parallel step 50.7 -> 67.7 ms at 8 queues)."""
+    import sys
+    import warnings
+    have = _os.environ.get("GPU_MAX_HW_QUEUES")
+    torch_mod = sys.modules.get("torch")
+    started = bool(torch_mod is not None and torch_mod.cuda.is_initialized())
+    if have is None and not started:
+        _os.environ["GPU_MAX_HW_QUEUES"] = str(_HW_QUEUES_WANTED)
+        return
+    try:
+        n = int(have) if have is not None else 4      # the runtime's default
+    except ValueError:
+        n = 0
+    if n < _HW_QUEUES_WANTED:
+        when = "the HIP runtime was already running when lidog_amd was imported" if started else \
+            f"GPU_MAX_HW_QUEUES={have} in the environment"
+        warnings.warn(f"lidog_amd: {when}, with {n} hardware queues; the step keeps up to five streams busy (compute, "
+                      f"weight gradients, coordinate maps, gradient buckets, RCCL) and streams that share a queue "
+                      f"serialise. Export GPU_MAX_HW_QUEUES={_HW_QUEUES_WANTED} before the process first touches the GPU.",
+                      RuntimeWarning, stacklevel=3)
+
+
+_hardware_queues()
 
 from . import me, bev, losses, trunk  # noqa: E402,F401
 from .minkunet import make_models  # noqa: E402

@@ -174,7 +174,6 @@ class _IdentityMap:
 
 
 _SIDE_STREAMS = {}
-_EXP_KEPT = {}
 # output-stationary 3^3 convolution (KernelMap.sorted): 0 = off, 1 = sparse symmetric maps (default), 2 = every one
 _SCONV_OS = int(os.environ.get("LIDOG_SCONV_OS", "1"))
 _SCONV_OS_DENSITY = float(os.environ.get("LIDOG_SCONV_OS_DENSITY", "6.0"))
@@ -342,16 +341,7 @@ class CoordinateManager:
             cm = cls(dev)
             cm.uniq, _ = cm.insert(coordinates)
             cm._own(coordinates)
-            keep = os.environ.get("LIDOG_EXP_KEEP_MAPS", "")   # timing experiment: these kernel maps are built once per batch
-            if keep:
-                cache = _EXP_KEPT.setdefault(id(coordinates), {})
-                for key, m in cache.items():
-                    cm.kmaps[key] = m
             cm.prefetch(trace)
-            if keep:
-                for key in list(cm.kmaps):
-                    if (keep == "stem" and key[2] == 5) or (keep == "k3" and key[2] == 3) or keep == "all":
-                        cache[key] = cm.kmaps[key]
             cm._ready = torch.cuda.Event()
             cm._ready.record(side)
         return cm

@@ -64,3 +64,15 @@ def test_rank_count_mismatch_is_refused_before_any_gpu_work(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
                        text=True, timeout=180)
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_too_few_hardware_queues_are_reported_at_import():
+    """lidog_amd sets GPU_MAX_HW_QUEUES=16 when nobody has (it only counts before the HIP runtime starts) and warns when
+    the environment already pins fewer queues than a step's streams need"""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    code = "import os, lidog_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    p = subprocess.run([sys.executable, "-W", "always", "-c", code], env=env, capture_output=True, text=True, cwd=REPO)
+    assert p.returncode == 0 and p.stdout.strip() == "16" and "hardware queues" not in p.stderr, p.stderr[-500:]
+    p = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="8"),
+                       capture_output=True, text=True, cwd=REPO)
+    assert p.returncode == 0 and p.stdout.strip() == "8" and "8 hardware queues" in p.stderr, p.stderr[-500:]
