@@ -66,6 +66,22 @@ class _CoordinatePrefetch:
                 (coords, ME.CoordinateManager.prepare(coords, self._trace, prefetch_ready))
 
 
+_PEER_CHECK_EVERY = int(_os.environ.get("LIDOG_PEER_CHECK_EVERY", "200"))
+
+
+def _check_transport(step):
+    """every LIDOG_PEER_CHECK_EVERY steps of a data-parallel run whose statistics take the peer all-reduce: its error
+    word, agreed over the ranks (comm.Transport.check: collective, synchronises with the device) -- a rank that stopped
+    sending is reported by every rank within that many steps instead of at the next epoch boundary"""
+    step._n_steps = getattr(step, "_n_steps", 0) + 1
+    if step._n_steps % _PEER_CHECK_EVERY or not (dist.is_available() and dist.is_initialized()):
+        return
+    from .comm import _TRANSPORTS
+    for tr in _TRANSPORTS.values():
+        if tr.peer is not None:
+            tr.check()
+
+
 class LiDOGStep(_CoordinatePrefetch):
     """PLTTrainer2D.training_step without the host round trips (coords / logits stay in HBM)."""
 
@@ -99,6 +115,7 @@ class LiDOGStep(_CoordinatePrefetch):
         total.backward()
         self.opt.step()
         self._after_step(prefetch, prefetch_ready)
+        _check_transport(self)
         return {"loss": total.detach(), "sem_loss": sem_loss.detach(), "bev_loss": bev_loss.detach()}
 
 
@@ -117,6 +134,7 @@ class SourceStep(_CoordinatePrefetch):
         loss.backward()
         self.opt.step()
         self._after_step(prefetch, prefetch_ready)
+        _check_transport(self)
         return {"loss": loss.detach()}
 
 
