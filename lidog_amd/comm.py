@@ -13,8 +13,8 @@ once per process group how they travel:
 * on top of either, with `LIDOG_PEER_ALLREDUCE=1` the statistics messages take the one-shot peer all-reduce of
   csrc/comm.hip (every rank pushes its vector into a mailbox in every peer's memory over its direct xGMI link and adds
   the N vectors in rank order) when every rank could open every other rank's mailbox and a start-up self-test gave the
-  right sums.  By default it is set up, self-tested and MEASURED by bench.py only (it has never run between two GPUs;
-  `=0` does not even set it up).
+  right sums.  `=probe` sets it up, self-tests it and lets bench.py MEASURE it next to RCCL; by default it is not even
+  set up (it has never run between two GPUs).
 * ``torch``: `torch.distributed` collectives of the group itself (any backend; gloo in the two-rank tests of this
   repository, which share one GPU where RCCL cannot put two ranks).  The executor reaches them through a host
   callback.
@@ -124,14 +124,15 @@ class Transport:
         nothing behind and the statistics go through the communicator / torch.distributed.
 
         LIDOG_PEER_ALLREDUCE: "1" = the step's statistics messages take it (where the set-up succeeded on every rank);
-        unset / "auto" = it is set up and self-tested but only MEASURED (`peer_probe`: bench.py times it next to RCCL) --
-        the step uses RCCL until the path has run on a real multi-GPU node (it never has: one-GPU boxes only);
-        "0" = not even set up.  In a one-rank group only "1" sets it up.
+        "probe" = it is set up and self-tested but only MEASURED (`peer_probe`: bench.py times it next to RCCL);
+        unset / "0" = not even set up: the path has never run between two GPUs (one-GPU boxes only), its self-test
+        already stores through hipIpc mappings of another device's memory, and the first multi-GPU run of this code must
+        not depend on that.  In a one-rank group only "1" sets it up.
         Fault injection (tests): LIDOG_PEER_FAULT="open:<rank>" makes that rank fail to open its peers' mailboxes;
         "skipflag:<rank>:<k>" makes that rank's k-th call after the self-test raise no flags."""
         self.peer, self.peer_probe, self.peer_max, self.peer_note = None, None, 0, "off"
-        want = os.environ.get("LIDOG_PEER_ALLREDUCE", "auto")
-        if want == "0" or not torch.cuda.is_available() or (self.world == 1 and want != "1"):
+        want = os.environ.get("LIDOG_PEER_ALLREDUCE", "0")
+        if want not in ("1", "probe") or not torch.cuda.is_available() or (self.world == 1 and want != "1"):
             return
         fault = os.environ.get("LIDOG_PEER_FAULT", "").split(":")
         L = _lib.load()
@@ -195,7 +196,7 @@ class Transport:
                 self.peer, self.peer_note = comm.value, "on"
             else:
                 self.peer_probe = comm.value
-                self.peer_note = "set up and self-tested, not used by the step (LIDOG_PEER_ALLREDUCE=1 switches it on)"
+                self.peer_note = "set up and self-tested, measured only (LIDOG_PEER_ALLREDUCE=1 switches it on)"
         else:
             if self.peer_note == "off":
                 self.peer_note = "another rank could not set it up"
