@@ -424,6 +424,12 @@ int lidog_sconv_os(const float *A, const int32_t *nbr, int64_t n, int32_t K, con
 /* lidog_sconv_os_stats: the forward form with the BatchNorm statistics of its result in the epilogue (one partial row
  * per tile, finished in-kernel; arguments as lidog_sconv_reduce_rows_stats).  ws: lidog_sconv_os_stats_ws(n, Cout) doubles. */
 int64_t lidog_sconv_os_stats_ws(int64_t n, int32_t C);
+/* lidog_sconv_os_bn: the forward form with an evaluation-mode BatchNorm (+ residual + ReLU) in the epilogue -- the
+ * validation path (arguments as lidog_sconv_reduce_rows_bn) */
+int lidog_sconv_os_bn(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                      const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias, int32_t Cin,
+                      int32_t Cout, const float *mean, const float *invstd, const float *w, const float *b,
+                      const float *residual, int32_t relu, float *out, void *stream);
 int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
                          const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias,
                          int32_t Cin, int32_t Cout, float *out, double *sums, double *ws, double count, float eps,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "lidog_kernel_map_sorted": [_p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p],
     "lidog_sconv_os": [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
     "lidog_sconv_os_stats_ws": [_i64, _i32],
+    "lidog_sconv_os_bn": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_sconv_os_stats": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],

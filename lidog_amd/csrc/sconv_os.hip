@@ -159,9 +159,13 @@ __device__ __forceinline__ void os_frag_load(const float *p, float (&f)[NT]) {
 // (The backward-statistics form of that pass was built here too and measured: its epilogue -- the producer's saved input
 // and mask re-read per tile row -- costs what the stand-alone reduction costs, 0.047 vs 0.055 ms on a stride-1
 // 96-channel layer, and its sums are not the operator path's bits; the data gradient therefore stays plain + addend.)
+//   mode 3 = an evaluation-mode BatchNorm (+ residual + ReLU) applied to the result before it is stored: the validation
+// path's fused form (sconv.hip:k_sconv_reduce_rows4_bn), same expression and operation order as bn.hip:k_bn_apply4.
 struct OsStats {
     int mode;
     StatsTail tail;
+    const float *bn_mean, *bn_invstd, *bn_w, *bn_b, *bn_res;
+    int bn_relu;
 };
 
 // Epilogue: bias, addend, the rows' store through `s_row` (canonical row of every tile
@@ -183,20 +187,35 @@ __device__ __forceinline__ void os_epilogue(f32x16 (&acc)[NT], const float (&bv)
     double s0[NT], s1[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) s0[t] = s1[t] = 0.0;
+    float e_m[NT], e_is[NT], e_w[NT], e_b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        e_m[t] = 0.f; e_is[t] = 1.f; e_w[t] = 1.f; e_b[t] = 0.f;
+    }
+    if (st.mode == 3) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = col0 + li * NT + t;
+            e_m[t] = st.bn_mean[c]; e_is[t] = st.bn_invstd[c]; e_w[t] = st.bn_w[c]; e_b[t] = st.bn_b[c];
+        }
+    }
     // rows in two batches of eight: the addend loads of a batch are issued before the first use -- unconditionally, a row
     // behind the end of the map reads row 0 and is masked afterwards (loads inside the per-row branch wait for memory
     // sixteen times in a row)
 #pragma unroll
     for (int eb = 0; eb < 16; eb += 8) {
         int dst[8];
-        float adv[8][NT];
+        float adv[8][NT], resv[8][NT];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = eb + u;
             dst[u] = s_row[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh];
             const size_t at = (size_t)(dst[u] < 0 ? 0 : dst[u]) * Cout + col0 + li * NT;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) adv[u][t] = addend ? addend[at + t] : 0.f;
+            for (int t = 0; t < NT; ++t) {
+                adv[u][t] = addend ? addend[at + t] : 0.f;
+                resv[u][t] = (st.mode == 3 && st.bn_res) ? st.bn_res[at + t] : 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -205,6 +224,15 @@ __device__ __forceinline__ void os_epilogue(f32x16 (&acc)[NT], const float (&bv)
             float v[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] = acc[t][e] + adv[u][t];   // no addend: + 0
+            if (st.mode == 3) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float y = (v[t] - e_m[t]) * e_is[t] * e_w[t] + e_b[t];
+                    if (st.bn_res) y += resv[u][t];
+                    if (st.bn_relu) y = fmaxf(y, 0.f);
+                    v[t] = y;
+                }
+            }
             if (ok) {
                 float *o = out + (size_t)dst[u] * Cout + col0 + li * NT;
                 if constexpr (NT == 4) {
@@ -226,7 +254,7 @@ __device__ __forceinline__ void os_epilogue(f32x16 (&acc)[NT], const float (&bv)
             }
         }
     }
-    if (st.mode != 0) {
+    if (st.mode == 1) {
         // the tile's column sums: the two row halves of a wave (lanes l, l + 32), then the four waves in order
         __syncthreads();   // every wave is done with the LDS that `red` aliases
 #pragma unroll
@@ -501,4 +529,20 @@ extern "C" int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t 
     int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats, st);
     if (rc) return rc;
     return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);
+}
+
+// Forward convolution with an evaluation-mode BatchNorm (+ residual + ReLU) in the epilogue: the validation path
+// (= lidog_sconv_gemm + lidog_sconv_reduce_rows_bn; utils/models/minkunet_bev.py:376-393, running statistics).
+extern "C" int lidog_sconv_os_bn(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                                 const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias,
+                                 int32_t Cin, int32_t Cout, const float *mean, const float *invstd, const float *w,
+                                 const float *b, const float *residual, int32_t relu, float *out, void *stream) {
+    if (n == 0) return 0;
+    LIDOG_REQUIRE(mean && invstd && w && b, "sconv_os_bn: BatchNorm vectors missing");
+    OsStats stats = {};
+    stats.mode = 3;
+    stats.bn_mean = mean; stats.bn_invstd = invstd; stats.bn_w = w; stats.bn_b = b; stats.bn_res = residual;
+    stats.bn_relu = relu;
+    return os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats,
+                     (hipStream_t)stream);
 }

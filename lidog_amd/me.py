@@ -1218,13 +1218,19 @@ class _ConvBase(nn.Module):
         xf = x.F.contiguous()
         W3 = self.kernel.detach().contiguous().view(m.K, self.in_channels, self.out_channels)
         Cin, Cout, dev = self.in_channels, self.out_channels, xf.device
-        T = torch.empty((m.P, Cout), dtype=torch.float32, device=dev)
-        _gemm(xf, m.pair_in, W3, None, m, Cin, Cout, T, None)
-        row_ptr, row_list = m.rows("out")
         invstd = torch.empty(Cout, dtype=torch.float32, device=dev)
         call("lidog_bn_eval_invstd", ptr(bn.running_var), float(bn.eps), Cout, ptr(invstd))
         out = torch.empty((m.n_out, Cout), dtype=torch.float32, device=dev)
         res = residual.F.contiguous() if residual is not None else None
+        srt = _os_rows(m, swap, Cin, Cout)
+        if srt is not None and not single_out:      # sorted rows: output-stationary kernel, same epilogue (same bits)
+            call("lidog_sconv_os_bn", ptr(xf), ptr(m.nbr), m.n_out, m.K, ptr(srt[0]), ptr(srt[1]), ptr(srt[2]), ptr(W3),
+                 ptr(self.bias.detach()) if self.bias is not None else None, Cin, Cout, ptr(bn.running_mean), ptr(invstd),
+                 ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(res), 1 if relu else 0, ptr(out))
+            return SparseTensor(out, coordinate_manager=cm, coordinate_map_key=s_out)
+        T = torch.empty((m.P, Cout), dtype=torch.float32, device=dev)
+        _gemm(xf, m.pair_in, W3, None, m, Cin, Cout, T, None)
+        row_ptr, row_list = m.rows("out")
         call("lidog_sconv_reduce_rows_bn", ptr(T), ptr(row_ptr), ptr(row_list), m.n_out, Cout,
              ptr(self.bias.detach()) if self.bias is not None else None, ptr(bn.running_mean), ptr(invstd),
              ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(res), 1 if relu else 0, ptr(out))

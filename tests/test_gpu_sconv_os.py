@@ -144,3 +144,31 @@ def test_statistics_form_and_bench_size_map():
         if rep:
             assert torch.equal(su2, keep)      # run-to-run identical sums
         keep = su2.clone()
+
+
+def test_evaluation_mode_batchnorm_epilogue_equals_the_two_pass_form():
+    """validation path: convolution + evaluation-mode BatchNorm + residual + ReLU in one launch, both forms, same bits"""
+    from lidog_amd._lib import call, ptr
+    coords = small_batch((5, 6), n_points=3000)
+    ME, cm = _setup(coords)
+    m = cm.kernel_map(1, 1, 3)
+    n, Cin, Cout = m.n_out, 64, 96
+    perm, wm, order = _sorted(m)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, Cin, generator=g).cuda()
+    W = (torch.randn(27, Cin, Cout, generator=g) * 0.1).cuda()
+    mean, var = torch.randn(Cout, generator=g).cuda(), (torch.rand(Cout, generator=g) + 0.5).cuda()
+    w, b = (torch.rand(Cout, generator=g) + 0.5).cuda(), torch.randn(Cout, generator=g).cuda()
+    res = torch.randn(n, Cout, generator=g).cuda()
+    invstd = torch.empty(Cout, device="cuda")
+    call("lidog_bn_eval_invstd", ptr(var), 1e-5, Cout, ptr(invstd))
+    T = torch.empty(m.P, Cout, device="cuda")
+    ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T, None)
+    rp, rl = m.rows("out")
+    for residual, relu in ((res, 1), (None, 1), (None, 0)):
+        o1, o2 = torch.empty(n, Cout, device="cuda"), torch.empty(n, Cout, device="cuda")
+        call("lidog_sconv_reduce_rows_bn", ptr(T), ptr(rp), ptr(rl), n, Cout, None, ptr(mean), ptr(invstd), ptr(w), ptr(b),
+             ptr(residual), relu, ptr(o1))
+        call("lidog_sconv_os_bn", ptr(x), ptr(m.nbr), n, 27, ptr(perm), ptr(wm), ptr(order), ptr(W), None, Cin, Cout,
+             ptr(mean), ptr(invstd), ptr(w), ptr(b), ptr(residual), relu, ptr(o2))
+        assert torch.equal(o1, o2)
