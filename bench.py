@@ -594,7 +594,13 @@ def main():
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
     if world > 1 or single_dp:
+        # orderly teardown: every rank has finished its collectives (barrier + synchronize), then this library's
+        # communicators and mailboxes go (ncclCommDestroy, hipIpcCloseMemHandle), then torch's group -- no RCCL object is
+        # left to the destructors at interpreter exit
         dist.barrier()
+        torch.cuda.synchronize()
+        from lidog_amd import comm as _comm
+        _comm.reset()
         dist.destroy_process_group()
     if peer_error:      # every rank holds the same verdict (Transport.check is collective): all leave non-zero
         sys.exit(f"bench.py: {peer_error}")

@@ -228,7 +228,8 @@ def transport(group=None):
 
 
 def reset():
-    """forget every transport (after dist.destroy_process_group(); the communicators are released)"""
+    """release every transport: this library's RCCL communicators and the peer mailboxes.  Call it on every rank once
+    all collectives are done (barrier + device synchronisation), before dist.destroy_process_group()."""
     L = _lib.load()
     for tr in _TRANSPORTS.values():
         for c in (tr.comm_bn, tr.comm_grad):

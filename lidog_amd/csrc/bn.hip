@@ -182,9 +182,22 @@ __global__ __launch_bounds__(256) void k_colreduce_plane(const float *__restrict
     double t0 = 0, t1 = 0;
     float m = 0.f, is = 1.f;
     if (MODE == 1) { m = mean[c]; is = invstd[c]; }
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-        red_terms<MODE>(x[base + i], MODE ? dy[base + i] : 0.f, (MODE && ry) ? ry[base + i] : 1.f, ry != nullptr, m, is,
-                        t0, t1);
+    // four elements of a thread in flight per round (1 024 consecutive floats per workgroup and round, every load
+    // issued before the first use; tail elements read the chunk's last one and are masked): the pass is a pure stream,
+    // and one 4-byte load per lane and iteration left it at 3 TB/s.  Per thread the terms are added in index order.
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 1024) {
+        float xv[4], gv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + 256 * u < i1 ? i + 256 * u : i1 - 1;
+            xv[u] = x[base + j];
+            gv[u] = MODE ? dy[base + j] : 0.f;
+            yv[u] = (MODE && ry) ? ry[base + j] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 256 * u < i1) red_terms<MODE>(xv[u], gv[u], yv[u], ry != nullptr, m, is, t0, t1);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         t0 += __shfl_down(t0, d);
@@ -475,11 +488,21 @@ __global__ __launch_bounds__(256) void k_bn_apply_plane(const float *__restrict_
     const int64_t chunk = (hw + gridDim.y - 1) / gridDim.y;
     const int64_t i0 = plane * hw + (int64_t)blockIdx.y * chunk;
     const int64_t i1 = (blockIdx.y + 1) * chunk < hw ? i0 + chunk : plane * hw + hw;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        float v = (x[i] - m) * is * ww + sh;   // same operation order as k_bn_apply
-        if (res) v += res[i];
-        if (relu) v = v > 0.f ? v : 0.f;
-        y[i] = v;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 1024) {   // four independent elements per thread and round
+        float xv[4], rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + 256 * u < i1 ? i + 256 * u : i1 - 1;
+            xv[u] = x[j];
+            rv[u] = res ? res[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = (xv[u] - m) * is * ww + sh;   // same operation order as k_bn_apply
+            if (res) v += rv[u];
+            if (relu) v = v > 0.f ? v : 0.f;
+            if (i + 256 * u < i1) y[i + 256 * u] = v;
+        }
     }
 }
 
@@ -498,12 +521,25 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_plane(const float *__restr
     const int64_t chunk = (hw + gridDim.y - 1) / gridDim.y;
     const int64_t i0 = plane * hw + (int64_t)blockIdx.y * chunk;
     const int64_t i1 = (blockIdx.y + 1) * chunk < hw ? i0 + chunk : plane * hw + hw;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        float g = dy[i];
-        if (ry && !(ry[i] > 0.f)) g = 0.f;
-        const float xh = (x[i] - m) * is;
-        dx[i] = (g - m0 - xh * m1) * is * ww;   // same operation order as k_bn_bwd_apply
-        if (dres) dres[i] = g;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 1024) {   // four independent elements per thread and round
+        float gv[4], xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + 256 * u < i1 ? i + 256 * u : i1 - 1;
+            gv[u] = dy[j];
+            xv[u] = x[j];
+            yv[u] = ry ? ry[j] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float g = gv[u];
+            if (ry && !(yv[u] > 0.f)) g = 0.f;
+            const float xh = (xv[u] - m) * is;
+            if (i + 256 * u < i1) {
+                dx[i + 256 * u] = (g - m0 - xh * m1) * is * ww;   // same operation order as k_bn_bwd_apply
+                if (dres) dres[i + 256 * u] = g;
+            }
+        }
     }
 }
 

@@ -255,6 +255,10 @@ def main(argv=None):
               resume=a.resume, auto_resume=a.auto_resume)
     fit.run()
     if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        from . import comm
+        comm.reset()                 # this library's RCCL communicators / mailboxes go before torch's group does
         dist.destroy_process_group()
 
 
