@@ -231,6 +231,11 @@ int64_t lidog_relu_bits_words(int64_t n, int32_t C);
 int lidog_bn_apply_bits(const float *x, int64_t n, int32_t C, int64_t hw, const float *mean, const float *invstd,
                         const float *w, const float *b, const float *residual, int32_t relu, float *y,
                         uint32_t *relu_bits, void *stream);
+/* SyncBatchNorm forward in one launch: mean / invstd / running statistics from the ALL-REDUCED sums (the row count
+ * behind them) + the apply pass; = lidog_bn_finalize(sums, -1, ...) followed by lidog_bn_apply_bits, bit for bit */
+int lidog_bn_apply_sync(const float *x, int64_t n, int32_t C, const double *sums, float eps, float momentum, float *mean,
+                        float *invstd, float *running_mean, float *running_var, const float *w, const float *b,
+                        const float *residual, int32_t relu, float *y, uint32_t *relu_bits, void *stream);
 int lidog_bn_bwd_reduce_bits(const float *dy, const float *x, const float *relu_y, const uint32_t *relu_bits, int64_t n,
                              int32_t C, int64_t hw, const float *mean, const float *invstd, double *sums, double *ws,
                              double count, float *dw, float *db, const float *relu_w, const float *relu_b,

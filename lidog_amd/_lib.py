@@ -113,6 +113,7 @@ SIGNATURES = {
     "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
     "lidog_conv2d_support_work": [_p, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_stream_create_cu_mask": [_p, _i32, ctypes.POINTER(ctypes.c_void_p)],
+    "lidog_bn_apply_sync": [_p, _i64, _i32, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "lidog_trunk_fusions": [_i32],
     "lidog_trunk_gemm_timing": [_i32],
     "lidog_trunk_gemm_timing_read": [_p],

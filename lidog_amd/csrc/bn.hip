@@ -468,6 +468,66 @@ __global__ __launch_bounds__(256) void k_bn_apply4(const float4 *__restrict__ x,
     }
 }
 
+// The same pass for SyncBatchNorm: mean / invstd are derived from the ALL-REDUCED (sum x, sum x^2, rows) vector inside
+// the launch -- k_bn_finalize's arithmetic, by the first C threads of every workgroup into LDS -- instead of by a
+// launch of their own between the all-reduce and this pass (62 per step on the dependent chain of a data-parallel
+// rank).  Workgroup 0 also stores mean / invstd (backward reads them) and updates the running statistics.
+__global__ __launch_bounds__(256) void k_bn_apply4_sync(const float4 *__restrict__ x, int64_t total4, int C4,
+                                                        const double *__restrict__ sums, float eps, float momentum,
+                                                        float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                                                        float *running_mean, float *running_var,
+                                                        const float4 *__restrict__ w, const float4 *__restrict__ b,
+                                                        const float4 *__restrict__ res, int relu,
+                                                        float4 *__restrict__ y, uint32_t *__restrict__ bits) {
+    extern __shared__ float s_ms[];   // [C] mean, [C] invstd
+    const int C = C4 * 4;
+    const double count = sums[2 * C];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double m = sums[c] / count;
+        double var = sums[C + c] / count - m * m;
+        if (var < 0) var = 0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+        s_ms[c] = mf;
+        s_ms[C + c] = isf;
+        if (blockIdx.x == 0) {
+            mean_out[c] = mf;
+            invstd_out[c] = isf;
+            if (running_mean) {
+                const double unb = (count > 1) ? var * count / (count - 1) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    const float4 *mean4 = reinterpret_cast<const float4 *>(s_ms), *is4 = reinterpret_cast<const float4 *>(s_ms + C);
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total4; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool ok = i < total4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            int c4 = (int)(i % C4);
+            v = x[i];
+            const float4 m = mean4[c4], s = is4[c4], ww = w[c4], bb = b[c4];
+            v.x = (v.x - m.x) * s.x * ww.x + bb.x;
+            v.y = (v.y - m.y) * s.y * ww.y + bb.y;
+            v.z = (v.z - m.z) * s.z * ww.z + bb.z;
+            v.w = (v.w - m.w) * s.w * ww.w + bb.w;
+            if (res) { float4 r = res[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            y[i] = v;
+        }
+        if (bits) {
+            uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            uint32_t wv = nib << (4 * (threadIdx.x & 7));
+            wv |= __shfl_xor(wv, 1);
+            wv |= __shfl_xor(wv, 2);
+            wv |= __shfl_xor(wv, 4);
+            if (ok && (threadIdx.x & 7) == 0) bits[i >> 3] = wv;
+        }
+    }
+}
+
 static unsigned ew_grid(int64_t n) {
     int64_t g = cdiv64(n, 256);
     return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -570,6 +630,27 @@ extern "C" int lidog_bn_apply_bits(const float *x, int64_t n, int32_t C, int64_t
     } else {
         k_bn_apply<<<ew_grid(total), 256, 0, st>>>(x, total, C, hw, mean, invstd, w, b, residual, relu, y);
     }
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// SyncBatchNorm forward, [rows, C] with C % 4 == 0: finalise (mean, invstd, running statistics) from the all-reduced
+// sums AND apply (+ residual + ReLU + bit mask) in one launch; the same results as lidog_bn_finalize(sums, -1, ...)
+// followed by lidog_bn_apply_bits.
+extern "C" int lidog_bn_apply_sync(const float *x, int64_t n, int32_t C, const double *sums, float eps, float momentum,
+                                   float *mean, float *invstd, float *running_mean, float *running_var, const float *w,
+                                   const float *b, const float *residual, int32_t relu, float *y, uint32_t *relu_bits,
+                                   void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(C % 4 == 0 && C >= 4 && C <= 4096 && sums && mean && invstd && w && b,
+                  "bn_apply_sync: [rows, C] with C a multiple of 4, <= 4096; sums / mean / invstd / w / b required");
+    LIDOG_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_apply_sync: both running statistics or none");
+    const int64_t total4 = n * C / 4;
+    // an empty shard still has to store mean / invstd and move the running statistics (one workgroup does)
+    const unsigned grid = total4 ? ew_grid(total4) : 1;
+    k_bn_apply4_sync<<<grid, 256, (size_t)2 * C * sizeof(float), st>>>(
+        (const float4 *)x, total4, C / 4, sums, eps, momentum, mean, invstd, running_mean, running_var, (const float4 *)w,
+        (const float4 *)b, (const float4 *)residual, relu, (float4 *)y, relu_bits);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

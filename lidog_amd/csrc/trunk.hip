@@ -405,10 +405,14 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
     };
     auto bn_part = [&](const Pending &pd) -> int {
         const int64_t *op = pd.op, *c = pd.c;
-        if (sync)   // the global count sits behind the sums (count <= 0: read from the device)
-            TRY(lidog_bn_finalize(pd.sums, -1.0, pd.Cout, pd.eps, pd.mom, pd.mean, pd.invstd, P<float>(c[TC_BNRM]),
-                                  P<float>(c[TC_BNRV]), stream));
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
+        if (sync) {   // mean / invstd / running statistics from the all-reduced sums (global count behind them) + the apply
+                      // pass, one launch
+            TRY(lidog_bn_apply_sync(pd.pre, pd.n, pd.Cout, pd.sums, pd.eps, pd.mom, pd.mean, pd.invstd,
+                                    P<float>(c[TC_BNRM]), P<float>(c[TC_BNRV]), P<const float>(c[TC_BNW]),
+                                    P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, stream));
+            return 0;
+        }
         TRY(lidog_bn_apply_bits(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
                                     P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, stream));
         return 0;
