@@ -441,6 +441,29 @@ int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t 
                          float momentum, float *mean, float *invstd, float *running_mean, float *running_var,
                          void *stream);
 
+/* ------------------------------------------------------------------ BatchNorm + ReLU applied in the consumer's staging
+ * conv1 -> BatchNorm -> ReLU -> conv2 inside a BasicBlock (ME modules/resnet_block.py as called from
+ * utils/models/minkunet_bev.py:312-371): conv2 is the only reader of the normalised rows, so they need not exist in
+ * memory.  The three forms below take the RAW output of conv1 as A plus conv1's BatchNorm vectors in_* [Cin] (batch mean,
+ * 1/sqrt(var + eps), weight, bias) and apply ((x - mean) * invstd) * w + b (and max(., 0) when in_relu) to every
+ * gathered row on its way into LDS -- lidog_bn_apply_bits' expression and operation order, so each form equals
+ * lidog_bn_apply_bits followed by the plain entry point bit for bit.  Matrix-core kernels only (channel counts multiples
+ * of 32, lidog_set_sparse_core(1)).  Other arguments as lidog_sconv_gemm / lidog_sconv_os_stats / lidog_sconv_wgrad. */
+int lidog_sconv_gemm_in_bn(const float *A, const int32_t *gather, const float *B, const float *bias,
+                           const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles,
+                           int32_t Cin, int32_t Cout, float *T, const int32_t *scatter, const float *in_mean,
+                           const float *in_invstd, const float *in_w, const float *in_b, int32_t in_relu, void *stream);
+int lidog_sconv_os_stats_in_bn(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                               const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias,
+                               int32_t Cin, int32_t Cout, float *out, double *sums, double *ws, double count, float eps,
+                               float momentum, float *mean, float *invstd, float *running_mean, float *running_var,
+                               const float *in_mean, const float *in_invstd, const float *in_w, const float *in_b,
+                               int32_t in_relu, void *stream);
+int lidog_sconv_wgrad_in_bn(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
+                            const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K, int32_t Cin,
+                            int32_t Cout, float *partial, float *gW, const float *in_mean, const float *in_invstd,
+                            const float *in_w, const float *in_b, int32_t in_relu, void *stream);
+
 /* ------------------------------------------------------------------ host-side tables of a kernel map (csrc/hostprep.hip)
  * Pure host code.  k_off_host [K+1]: the rule book's offsets (lidog_kernel_map_pairs' k_off copied to the host).
  * lidog_tiles_host: the (tile_k, tile_row0, tile_rows) descriptors lidog_sconv_gemm takes, `tile_rows` (128) pairs per
@@ -517,7 +540,8 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
 /* Fusions the executor applies on top of the operator path's launch sequence (bit mask; results are bit-identical
  * either way): 1 = BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction
  * (lidog_sconv_reduce_rows_bwdstats); 2 = the ReLU masks of BatchNorm + residual + ReLU layers kept as bits
- * (lidog_bn_apply_bits).  mask >= 0 sets it; returns the previous mask.  Set it between passes, not between a forward
+ * (lidog_bn_apply_bits); 4 = the BatchNorm + ReLU between the two convolutions of a block applied in the second one's
+ * staging (lidog_sconv_*_in_bn) instead of by a pass of its own.  mask >= 0 sets it; returns the previous mask.  Set it between passes, not between a forward
  * pass and its backward pass. */
 /* a stream restricted to the compute units whose bits are set (hipExtStreamCreateWithCUMask): lets the caller keep the
  * weight-gradient stream of the backward pass off part of the chip (lidog_amd.me._WgradLane, LIDOG_LANE_CU_MASK) */

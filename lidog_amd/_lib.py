@@ -44,6 +44,10 @@ SIGNATURES = {
     "lidog_sconv_os_bn": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_sconv_os_stats": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_gemm_in_bn": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
+    "lidog_sconv_os_stats_in_bn": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p,
+                                   _p, _p, _p, _p, _i32, _p],
+    "lidog_sconv_wgrad_in_bn": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
     "lidog_set_sparse_core": [_i32],
     "lidog_get_sparse_core": [],
@@ -131,7 +135,7 @@ _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "
 
 # lidog_abi_version() of the library these signatures were written against: a stale .so (or a header an external caller
 # compiled against long ago) would take mis-sized arguments without any diagnostic
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

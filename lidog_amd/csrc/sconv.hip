@@ -272,6 +272,24 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_cin8(const float *__restrict
     }
 }
 
+// The gathered GEMM with the BatchNorm (+ ReLU) of the layer BEFORE applied to the rows as they are gathered: A is that
+// layer's raw convolution output, in_* its batch statistics and affine parameters [Cin] (= lidog_bn_apply_bits followed by
+// lidog_sconv_gemm, bit for bit).  Matrix-core kernels only: Cin, Cout multiples of 32, lidog_set_sparse_core(1).
+extern "C" int lidog_sconv_gemm_in_bn(const float *A, const int32_t *gather, const float *B, const float *bias,
+                                      const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows,
+                                      int32_t n_tiles, int32_t Cin, int32_t Cout, float *T, const int32_t *scatter,
+                                      const float *in_mean, const float *in_invstd, const float *in_w, const float *in_b,
+                                      int32_t in_relu, void *stream) {
+    if (n_tiles == 0) return 0;
+    LIDOG_REQUIRE(in_mean && in_invstd && in_w && in_b, "sconv_gemm_in_bn: input BatchNorm vectors missing");
+    LIDOG_REQUIRE(g_sparse_core == 1 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
+                  "sconv_gemm_in_bn: matrix-core kernels only (channel counts multiples of 32; got %d -> %d)", Cin, Cout);
+    lidog_launch_gemm_mfma(A, gather, B, bias, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, scatter,
+                           InBn{in_mean, in_invstd, in_w, in_b, in_relu}, (hipStream_t)stream);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
                                 const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows,
                                 int32_t n_tiles, int32_t Cin, int32_t Cout, float *T, const int32_t *scatter,
@@ -280,7 +298,8 @@ extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const flo
     if (n_tiles == 0) return 0;
     LIDOG_REQUIRE(Cin > 0 && Cout > 0, "sconv_gemm: bad channel counts %d %d", Cin, Cout);
     if (g_sparse_core == 1 && Cin % 32 == 0 && Cout % 32 == 0) {
-        lidog_launch_gemm_mfma(A, gather, B, bias, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, scatter, st);
+        lidog_launch_gemm_mfma(A, gather, B, bias, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, scatter,
+                               InBn{nullptr, nullptr, nullptr, nullptr, 0}, st);
         LIDOG_LAUNCH_CHECK();
         return 0;
     }
@@ -1175,9 +1194,9 @@ extern "C" int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_item
     return n_items;
 }
 
-extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
-                                 const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K,
-                                 int32_t Cin, int32_t Cout, float *partial, float *gW, void *stream) {
+static int sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
+                       const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K, int32_t Cin,
+                       int32_t Cout, float *partial, float *gW, InBn in_bn, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(K >= 1 && n_items >= 0, "sconv_wgrad: bad K / n_items");
     LIDOG_REQUIRE(n_items == 0 || partial != nullptr, "sconv_wgrad: partial workspace missing");
@@ -1186,7 +1205,7 @@ extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const fl
     if (n_items > 0) {
         if (g_sparse_core == 1 && rm && cn) {
             per = lidog_wgrad_mfma_slabs(Cin, Cout, 1);
-            lidog_launch_wgrad_mfma(A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial, st);
+            lidog_launch_wgrad_mfma(A, pair_a, G, pair_g, items, n_items, Cin, Cout, partial, in_bn, st);
         } else if (rm && cn) {
             dim3 grid((unsigned)n_items, (unsigned)((Cin / (16 * rm)) * (Cout / (16 * cn))));
             switch (rm) {
@@ -1216,6 +1235,28 @@ extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const fl
         k_items_sum<<<dim3((unsigned)cdiv64(n, 64), (unsigned)K), 256, 0, st>>>(partial, item_off, per, n, gW);
     LIDOG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
+                                 const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K,
+                                 int32_t Cin, int32_t Cout, float *partial, float *gW, void *stream) {
+    return sconv_wgrad(A, pair_a, G, pair_g, items, n_items, item_off, K, Cin, Cout, partial, gW,
+                       InBn{nullptr, nullptr, nullptr, nullptr, 0}, stream);
+}
+
+// The weight gradient of a convolution whose input is BatchNorm (+ ReLU) of A: A is the raw output of the layer before,
+// in_* its batch statistics and affine parameters [Cin]; the normalised rows exist only in LDS (= the weight gradient
+// over lidog_bn_apply_bits' output, bit for bit).  Matrix-core kernels only.
+extern "C" int lidog_sconv_wgrad_in_bn(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
+                                       const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K,
+                                       int32_t Cin, int32_t Cout, float *partial, float *gW, const float *in_mean,
+                                       const float *in_invstd, const float *in_w, const float *in_b, int32_t in_relu,
+                                       void *stream) {
+    LIDOG_REQUIRE(in_mean && in_invstd && in_w && in_b, "sconv_wgrad_in_bn: input BatchNorm vectors missing");
+    LIDOG_REQUIRE(g_sparse_core == 1 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
+                  "sconv_wgrad_in_bn: matrix-core kernels only (channel counts multiples of 32; got %d -> %d)", Cin, Cout);
+    return sconv_wgrad(A, pair_a, G, pair_g, items, n_items, item_off, K, Cin, Cout, partial, gW,
+                       InBn{in_mean, in_invstd, in_w, in_b, in_relu}, stream);
 }
 
 // ------------------------------------------------------------------ Wt[k][co][ci] = W[k][ci][co]

@@ -64,7 +64,9 @@ __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
 // Tile 128 pair-rows x 32*NT columns; wave w owns rows [32w, 32w+32) and all NT column tiles.
 // MINW: waves per SIMD the register allocation must leave room for (1 = whatever the kernel likes: 140-144 registers,
 // three workgroups per CU; 4 = at most 128 registers, four workgroups per CU -- spill-free for the 96-column case only)
-template <int NT, int MINW = 1>
+// FOLD: the producer's BatchNorm + ReLU applied to the gathered rows on their way into LDS (InBn, sconv_mfma.h); its four
+// per-channel vectors for the chunk travel with the chunk's prefetch (16 registers: 160 of the 170 three workgroups allow)
+template <int NT, int MINW = 1, bool FOLD = false>
 __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__restrict__ A,
                                                          const int32_t *__restrict__ gather,
                                                          const float *__restrict__ B,
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
                                                          const int32_t *__restrict__ tile_row0,
                                                          const int32_t *__restrict__ tile_rows, int Cin, int Cout,
                                                          float *__restrict__ T,
-                                                         const int32_t *__restrict__ scatter) {
+                                                         const int32_t *__restrict__ scatter, InBn in_bn) {
     constexpr int TN = 32 * NT;
     constexpr int BV = (MG_BK * TN / 4) / 256;  // float4 of B per thread per chunk (1..4)
     __shared__ float As[MG_TM * MG_SA];
@@ -107,6 +109,8 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
     // rb0..rb3 are separate named registers on purpose: as an array (float4 rb[BV]) hipcc keeps the B
     // staging values in scratch memory for BV >= 2
     float4 ra[4], rb0, rb1, rb2, rb3;
+    float4 pm, ps, pw, pb;
+    pm = ps = pw = pb = make_float4(0.f, 0.f, 0.f, 0.f);
     rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define MG_LOADB(J, R)                                                                      \
     if constexpr (BV > J) {                                                                 \
@@ -118,22 +122,26 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
     if constexpr (BV > J) *reinterpret_cast<float4 *>(&Bs[(tid + 256 * J) * 4]) = R;
     // the 4 gathered rows this thread stages (8 lanes fetch one 128-B line of a row), fixed for the tile
     const float *a_row[4];
-    bool a_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int f = tid + 256 * j;
         int r = f >> 3;
         int src = scatter ? s_src[r] : (r < rows ? (gather ? gather[row0 + r] : row0 + r) : -1);
-        a_ok[j] = src >= 0;
         a_row[j] = A + (size_t)(src < 0 ? 0 : src) * Cin + (f & 7) * 4;
     }
     auto load_chunk = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // unconditional load (a branch around the load would serialise the gather); rows past the end of
-            // the tile are zeroed when the chunk is written to LDS -- a select here would make the wave wait
-            // for the gather before its MFMA phase instead of after it
+            // the tile read row 0
             ra[j] = *reinterpret_cast<const float4 *>(a_row[j] + kb);
+        }
+        if constexpr (FOLD) {   // the thread's four rows share one channel quad: (tid & 7) * 4 of the chunk
+            const int c = kb + (tid & 7) * 4;
+            pm = *reinterpret_cast<const float4 *>(in_bn.mean + c);
+            ps = *reinterpret_cast<const float4 *>(in_bn.invstd + c);
+            pw = *reinterpret_cast<const float4 *>(in_bn.w + c);
+            pb = *reinterpret_cast<const float4 *>(in_bn.b + c);
         }
         MG_LOADB(0, rb0) MG_LOADB(1, rb1) MG_LOADB(2, rb2) MG_LOADB(3, rb3)
     };
@@ -143,11 +151,14 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
             int f = tid + 256 * j;
             int r = f >> 3, q = f & 7;
             const int o = r * MG_SA + q * 4;
-            const bool ok = a_ok[j];
-            As[o] = ok ? ra[j].x : 0.f;
-            As[o + 1] = ok ? ra[j].y : 0.f;
-            As[o + 2] = ok ? ra[j].z : 0.f;
-            As[o + 3] = ok ? ra[j].w : 0.f;
+            float4 v = ra[j];
+            if constexpr (FOLD) v = in_bn_apply(v, pm, ps, pw, pb, in_bn.relu);
+            // rows past the end of the tile hold row 0's values: a row of A only reaches the same row of the result, and
+            // those rows are never stored (zeroing them cost 16 selects per chunk: 48.34 -> 48.28 ms per step)
+            As[o] = v.x;
+            As[o + 1] = v.y;
+            As[o + 2] = v.z;
+            As[o + 3] = v.w;
         }
         MG_STOREB(0, rb0) MG_STOREB(1, rb1) MG_STOREB(2, rb2) MG_STOREB(3, rb3)
     };
@@ -248,12 +259,22 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
 
 int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B, const float *bias,
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
-                           int Cin, int Cout, float *T, const int32_t *scatter, hipStream_t st) {
+                           int Cin, int Cout, float *T, const int32_t *scatter, InBn in_bn, hipStream_t st) {
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)n_tiles, (unsigned)(Cout / (32 * nt)));
-#define LAUNCH(NT_, MW_)                                                                                          \
-    k_sconv_gemm_mfma<NT_, MW_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, \
-                                                      scatter)
+#define LAUNCHF(NT_, MW_, F_)                                                                                     \
+    k_sconv_gemm_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, \
+                                                          T, scatter, in_bn)
+#define LAUNCH(NT_, MW_) LAUNCHF(NT_, MW_, false)
+    if (in_bn.mean) {
+        switch (nt) {
+            case 4: LAUNCHF(4, 1, true); break;
+            case 3: LAUNCHF(3, 1, true); break;
+            case 2: LAUNCHF(2, 1, true); break;
+            default: LAUNCHF(1, 1, true);
+        }
+        return 0;
+    }
     // the 96-column kernel fits 128 registers without spilling: four workgroups per CU instead of three, measured in
     // the training step (same box, alternating): 49.88 / 49.84 -> 49.76 / 49.74 ms; LIDOG_GEMM3_WAVES=1 switches back
     static int waves3 = -1;
@@ -271,6 +292,7 @@ int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B
         default: LAUNCH(1, 1);
     }
 #undef LAUNCH
+#undef LAUNCHF
     return 0;
 }
 
@@ -280,15 +302,20 @@ int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B
 // are fewer tiles than waves the waves form NGRP groups that each take every NGRP-th row pair and emit
 // their own partial slab.
 #define MW_R 32
-template <int MT, int NT, int NW, int NGRP>
-__global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__restrict__ A,
+// FOLD: the A rows are the raw output of the layer before; its BatchNorm + ReLU (InBn) is applied when they are written
+// to LDS, from a copy of the four per-channel vectors of this workgroup's input-channel range kept in LDS
+// (the 128 x 128 tile with FOLD is held to the 170 registers of three workgroups per CU, as without)
+template <int MT, int NT, int NW, int NGRP, bool FOLD = false>
+__global__ __launch_bounds__(64 * NW, (FOLD && MT * NT == 16) ? 3 : 1) void k_sconv_wgrad_mfma(const float *__restrict__ A,
                                                               const int32_t *__restrict__ pa,
                                                               const float *__restrict__ G,
                                                               const int32_t *__restrict__ pg,
                                                               const int32_t *__restrict__ items, int n_items,
-                                                              int Cin, int Cout, float *__restrict__ partial) {
+                                                              int Cin, int Cout, float *__restrict__ partial,
+                                                              InBn in_bn) {
     constexpr int TM = 32 * MT, TN = 32 * NT, NTH = 64 * NW;
     constexpr int TILES = MT * NT;
+    __shared__ __attribute__((aligned(16))) float s_par[FOLD ? 4 * TM : 4];
     constexpr int WPG = NW / NGRP;            // waves per group
     constexpr int TPW = (TILES + WPG - 1) / WPG;  // tiles per wave
     __shared__ __attribute__((aligned(16))) float As[MW_R * TM];
@@ -366,6 +393,14 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
         load_rows(p0);
         load_idx(p0 + MW_R);
     }
+    if constexpr (FOLD) {   // visible to every thread behind the first barrier of the loop
+        for (int i = tid; i < TM; i += NTH) {
+            s_par[i] = in_bn.mean[ci0 + i];
+            s_par[TM + i] = in_bn.invstd[ci0 + i];
+            s_par[2 * TM + i] = in_bn.w[ci0 + i];
+            s_par[3 * TM + i] = in_bn.b[ci0 + i];
+        }
+    }
     for (int64_t p = p0; p < p1; p += MW_R) {
         __syncthreads();
 #pragma unroll
@@ -375,7 +410,15 @@ __global__ __launch_bounds__(64 * NW) void k_sconv_wgrad_mfma(const float *__res
             // load would make the wave wait for the gather before its MFMA phase instead of after it
             // (componentwise selects: a ternary on a whole float4 goes through scratch memory)
             const bool ok = p + f / (TM / 4) < p1;
-            if (f < MW_R * TM / 4) *reinterpret_cast<float4 *>(&As[f * 4]) = make_float4(ok ? ra[j].x : 0.f, ok ? ra[j].y : 0.f, ok ? ra[j].z : 0.f, ok ? ra[j].w : 0.f);
+            float4 v = ra[j];
+            if constexpr (FOLD) {
+                const int c = ((f < MW_R * TM / 4 ? f : MW_R * TM / 4 - 1) % (TM / 4)) * 4;
+                v = in_bn_apply(v, *reinterpret_cast<const float4 *>(&s_par[c]),
+                                *reinterpret_cast<const float4 *>(&s_par[TM + c]),
+                                *reinterpret_cast<const float4 *>(&s_par[2 * TM + c]),
+                                *reinterpret_cast<const float4 *>(&s_par[3 * TM + c]), in_bn.relu);
+            }
+            if (f < MW_R * TM / 4) *reinterpret_cast<float4 *>(&As[f * 4]) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll
         for (int j = 0; j < GV; ++j) {
@@ -458,16 +501,21 @@ int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_items) {
 
 template <int MT, int NT, int NW, int NGRP>
 static void launch_wg(dim3 grid, hipStream_t st, const float *A, const int32_t *pa, const float *G, const int32_t *pg,
-                      const int32_t *items, int n_items, int Cin, int Cout, float *partial) {
-    k_sconv_wgrad_mfma<MT, NT, NW, NGRP><<<grid, 64 * NW, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout, partial);
+                      const int32_t *items, int n_items, int Cin, int Cout, float *partial, InBn in_bn) {
+    if (in_bn.mean)
+        k_sconv_wgrad_mfma<MT, NT, NW, NGRP, true><<<grid, 64 * NW, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout,
+                                                                             partial, in_bn);
+    else
+        k_sconv_wgrad_mfma<MT, NT, NW, NGRP, false><<<grid, 64 * NW, 0, st>>>(A, pa, G, pg, items, n_items, Cin, Cout,
+                                                                              partial, in_bn);
 }
 
 int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, const int32_t *pg,
-                            const int32_t *items, int n_items, int Cin, int Cout, float *partial,
+                            const int32_t *items, int n_items, int Cin, int Cout, float *partial, InBn in_bn,
                             hipStream_t st) {
     int mt = tile32(Cin), nt = tile32(Cout);
     dim3 grid((unsigned)n_items, (unsigned)((Cin / (32 * mt)) * (Cout / (32 * nt))));
-#define WG(MT_, NT_, NW_, NG_) launch_wg<MT_, NT_, NW_, NG_>(grid, st, A, pa, G, pg, items, n_items, Cin, Cout, partial)
+#define WG(MT_, NT_, NW_, NG_) launch_wg<MT_, NT_, NW_, NG_>(grid, st, A, pa, G, pg, items, n_items, Cin, Cout, partial, in_bn)
     switch (mt * 10 + nt) {
         case 11: WG(1, 1, 4, 4); break;
         case 12: WG(1, 2, 4, 2); break;

@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "sconv_mfma.h"
 #include "stats_tail.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -280,7 +281,9 @@ __device__ __forceinline__ void os_epilogue(f32x16 (&acc)[NT], const float (&bv)
 
 // MFMA 32x32x2 lane maps as in sconv_mfma.hip: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 // D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5).  MFMA column tile t of a wave = columns {li * NT + t}.
-template <int NT, int MINW>
+// FOLD: the input rows are the raw output of the layer before; its BatchNorm + ReLU (InBn, sconv_mfma.h) is applied while
+// they are staged (a missing neighbour stays an exact zero).
+template <int NT, int MINW, bool FOLD = false>
 __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__restrict__ A, const int32_t *__restrict__ nbr,
                                                        int64_t n, int K, const int32_t *__restrict__ perm,
                                                        const uint32_t *__restrict__ wave_masks,
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                                                        const float *__restrict__ W, int reverse,
                                                        const float *__restrict__ bias,
                                                        const float *__restrict__ addend, int Cin, int Cout,
-                                                       float *__restrict__ out, OsStats st) {
+                                                       float *__restrict__ out, OsStats st, InBn in_bn) {
     constexpr int TN = 32 * NT;
     constexpr int BV = (OS_BK * TN / 4) / 256;
     __shared__ float As[OS_TM * OS_SA];
@@ -332,6 +335,8 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
 
     // staging: thread handles the float4 (tid & 7) of tile rows (tid >> 3) + 32 j
     float4 ra[4], rb0, rb1, rb2, rb3;
+    float4 pm, ps, pw, pb;
+    pm = ps = pw = pb = make_float4(0.f, 0.f, 0.f, 0.f);
     rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *a_row[4];
     bool ok_cur[4], ok_nxt[4];
@@ -356,6 +361,12 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
         const float *Bk = W + (size_t)(reverse ? K - 1 - k : k) * Cin * Cout + col0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4 *>(a_row[j] + kb);
+        if constexpr (FOLD) {   // the thread's four rows share the channel quad q4 of the chunk
+            pm = *reinterpret_cast<const float4 *>(in_bn.mean + kb + q4);
+            ps = *reinterpret_cast<const float4 *>(in_bn.invstd + kb + q4);
+            pw = *reinterpret_cast<const float4 *>(in_bn.w + kb + q4);
+            pb = *reinterpret_cast<const float4 *>(in_bn.b + kb + q4);
+        }
         OS_LOADB(0, rb0) OS_LOADB(1, rb1) OS_LOADB(2, rb2) OS_LOADB(3, rb3)
     };
     auto next_offset = [&](uint32_t rem) { return reverse ? 31 - __builtin_clz(rem) : __builtin_ctz(rem); };
@@ -376,10 +387,12 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                 const int f = tid + 256 * j;
                 const int o = (f >> 3) * OS_SA + (f & 7) * 4;
                 const bool ok = ok_cur[j];
-                As[o] = ok ? ra[j].x : 0.f;
-                As[o + 1] = ok ? ra[j].y : 0.f;
-                As[o + 2] = ok ? ra[j].z : 0.f;
-                As[o + 3] = ok ? ra[j].w : 0.f;
+                float4 v = ra[j];
+                if constexpr (FOLD) v = in_bn_apply(v, pm, ps, pw, pb, in_bn.relu);
+                As[o] = ok ? v.x : 0.f;
+                As[o + 1] = ok ? v.y : 0.f;
+                As[o + 2] = ok ? v.z : 0.f;
+                As[o + 3] = ok ? v.w : 0.f;
             }
             OS_STOREB(0, rb0) OS_STOREB(1, rb1) OS_STOREB(2, rb2) OS_STOREB(3, rb3)
             __syncthreads();
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
 static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const int32_t *perm,
                      const uint32_t *wave_masks, const int32_t *tile_order, const float *W, int reverse,
                      const float *bias, const float *addend, int Cin, int Cout, float *out, const OsStats &stats,
-                     hipStream_t st) {
+                     hipStream_t st, InBn in_bn = InBn{nullptr, nullptr, nullptr, nullptr, 0}) {
     LIDOG_REQUIRE(K >= 1 && K <= OS_MAXK && Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0,
                   "sconv_os: K <= %d, channel counts multiples of 32 (got K %d, %d -> %d)", OS_MAXK, K, Cin, Cout);
     LIDOG_REQUIRE(A && nbr && perm && wave_masks && tile_order && W && out, "sconv_os: null argument");
@@ -467,9 +480,20 @@ static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const
     }
     if (force_nt >= 1 && force_nt <= 4 && Cout % (32 * force_nt) == 0) nt = force_nt;
     dim3 grid((unsigned)(os_pad(n) / OS_TM), (unsigned)(Cout / (32 * nt)));
-#define OS_LAUNCH(NT_, MW_)                                                                                         \
-    k_sconv_os_mfma<NT_, MW_><<<grid, 256, 0, st>>>(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, addend, \
-                                                    Cin, Cout, out, stats)
+#define OS_LAUNCHF(NT_, MW_, F_)                                                                                 \
+    k_sconv_os_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, \
+                                                        addend, Cin, Cout, out, stats, in_bn)
+#define OS_LAUNCH(NT_, MW_) OS_LAUNCHF(NT_, MW_, false)
+    if (in_bn.mean) {   // 16 more registers: the 64-column kernel no longer fits four waves per SIMD
+        switch (nt) {
+            case 4: OS_LAUNCHF(4, 2, true); break;
+            case 3: OS_LAUNCHF(3, 2, true); break;
+            case 2: OS_LAUNCHF(2, 2, true); break;
+            default: OS_LAUNCHF(1, 4, true);
+        }
+        LIDOG_LAUNCH_CHECK();
+        return 0;
+    }
     static int minw = -1;   // A/B: LIDOG_OS_MINW=3 compiles the 96- / 128-column kernels for three waves per SIMD (spills)
     if (minw < 0) {
         const char *e = getenv("LIDOG_OS_MINW");
@@ -488,6 +512,7 @@ static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const
         default: OS_LAUNCH(1, 4);
     }
 #undef OS_LAUNCH
+#undef OS_LAUNCHF
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -512,11 +537,10 @@ extern "C" int64_t lidog_sconv_os_stats_ws(int64_t n, int32_t C) {
 
 // Forward convolution + the BatchNorm statistics of its result (= lidog_sconv_gemm + lidog_sconv_reduce_rows_stats):
 // sums [2 Cout + 1], ws: lidog_sconv_os_stats_ws doubles; count / eps / momentum / mean / ... as lidog_bn_stats.
-extern "C" int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
-                                    const uint32_t *wave_masks, const int32_t *tile_order, const float *W,
-                                    const float *bias, int32_t Cin, int32_t Cout, float *out, double *sums, double *ws,
-                                    double count, float eps, float momentum, float *mean, float *invstd,
-                                    float *running_mean, float *running_var, void *stream) {
+static int os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                    const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias, int32_t Cin,
+                    int32_t Cout, float *out, double *sums, double *ws, double count, float eps, float momentum,
+                    float *mean, float *invstd, float *running_mean, float *running_var, InBn in_bn, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     LIDOG_REQUIRE(sums && ws, "sconv_os_stats: sums / workspace missing");
     LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_os_stats: finalising needs the row count");
@@ -526,9 +550,33 @@ extern "C" int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t 
     stats.mode = 1;
     BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
     if (lidog_stats_tail_make(&stats.tail, ws, sums, count, Cout, fin, st)) return 1;
-    int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats, st);
+    int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats, st, in_bn);
     if (rc) return rc;
     return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);
+}
+
+extern "C" int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                                    const uint32_t *wave_masks, const int32_t *tile_order, const float *W,
+                                    const float *bias, int32_t Cin, int32_t Cout, float *out, double *sums, double *ws,
+                                    double count, float eps, float momentum, float *mean, float *invstd,
+                                    float *running_mean, float *running_var, void *stream) {
+    return os_stats(A, nbr, n, K, perm, wave_masks, tile_order, W, bias, Cin, Cout, out, sums, ws, count, eps, momentum,
+                    mean, invstd, running_mean, running_var, InBn{nullptr, nullptr, nullptr, nullptr, 0}, stream);
+}
+
+// The same with the BatchNorm (+ ReLU) of the layer BEFORE applied to the input rows as they are gathered: A is that
+// layer's raw convolution output, in_* its batch statistics and affine parameters [Cin] -- conv -> BN -> ReLU -> conv
+// without the normalised copy in between (= lidog_bn_apply_bits followed by lidog_sconv_os_stats, bit for bit).
+extern "C" int lidog_sconv_os_stats_in_bn(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
+                                          const uint32_t *wave_masks, const int32_t *tile_order, const float *W,
+                                          const float *bias, int32_t Cin, int32_t Cout, float *out, double *sums,
+                                          double *ws, double count, float eps, float momentum, float *mean, float *invstd,
+                                          float *running_mean, float *running_var, const float *in_mean,
+                                          const float *in_invstd, const float *in_w, const float *in_b, int32_t in_relu,
+                                          void *stream) {
+    LIDOG_REQUIRE(in_mean && in_invstd && in_w && in_b, "sconv_os_stats_in_bn: input BatchNorm vectors missing");
+    return os_stats(A, nbr, n, K, perm, wave_masks, tile_order, W, bias, Cin, Cout, out, sums, ws, count, eps, momentum,
+                    mean, invstd, running_mean, running_var, InBn{in_mean, in_invstd, in_w, in_b, in_relu}, stream);
 }
 
 // Forward convolution with an evaluation-mode BatchNorm (+ residual + ReLU) in the epilogue: the validation path

@@ -205,7 +205,44 @@ inline const int32_t *tile_row(const int64_t *m, int r) { return P<const int32_t
 // Fusions the executor applies on top of the operator path's launch sequence (results stay bit-identical):
 //   1 = BatchNorm-backward statistics in the epilogue of the data-gradient reduction that produces the gradient
 //   2 = ReLU masks of the BatchNorm + residual + ReLU layers kept as bits (backward reads 1/32 of the saved output)
-int g_fusions = 3;
+//   4 = BatchNorm + ReLU between the two convolutions of a block applied in the second one's staging (in_bn_of below)
+int g_fusions = 7;
+
+// The BatchNorm + ReLU of op o needs no pass of its own when its output has exactly one reader and that reader is a 3^3
+// convolution + BatchNorm on the matrix-core kernels (conv1 -> BN -> ReLU -> conv2 of a BasicBlock): the reader takes
+// the raw convolution output and the BatchNorm vectors instead (lidog_sconv_*_in_bn), forward and weight gradient; the
+// BatchNorm's own backward pass already works from the raw output (mask recomputed from it).  Returns the reader's op
+// index, or -1.  Pure function of the tables: the forward and the backward pass decide alike.
+int in_bn_reader(const Ctx &ctx, int o) {
+    if (!(g_fusions & 4) || lidog_get_sparse_core() != 1) return -1;
+    const int64_t *op = ctx.ops + (int64_t)o * TO_COLS;
+    if (op[TO_TYPE] != OP_CONVBN || !op[TO_RELU] || op[TO_RES] >= 0) return -1;
+    const int64_t out = op[TO_OUT];
+    if (ctx.bufs[out * TB_COLS + TB_EXT] >= 0) return -1;
+    int reader = -1, users = 0;
+    for (int q = 0; q < ctx.n_ops; ++q) {
+        const int64_t *u = ctx.ops + (int64_t)q * TO_COLS;
+        if (u[TO_TYPE] == OP_CAT) {
+            if (u[TO_IN] == out || u[TO_B] == out) ++users;
+            continue;
+        }
+        if (u[TO_TYPE] == OP_CONVBN && u[TO_RES] == out) ++users;
+        if (u[TO_IN] == out) {
+            ++users;
+            reader = q;
+        }
+    }
+    if (users != 1 || reader < o) return -1;
+    const int64_t *u = ctx.ops + (int64_t)reader * TO_COLS;
+    const int64_t *c = ctx.convs + u[TO_CONV] * TC_COLS;
+    if (u[TO_TYPE] != OP_CONVBN || c[TC_KIND] != KIND_K3 || c[TC_CIN] % 32 || c[TC_COUT] % 32) return -1;
+    return reader;
+}
+
+// what the reader of a folded BatchNorm is handed instead of the normalised rows
+struct InBnArgs {
+    const float *pre, *mean, *invstd, *w, *b;
+};
 
 // Optional timing of the gathered GEMM's launches (bench.py's roofline figure): HIP events on the launch stream around
 // every lidog_sconv_gemm call of the executor, with the launch's algorithmic FLOPs and bytes (every distinct input row
@@ -236,7 +273,8 @@ hipEvent_t timing_event() {
 
 // n_src: rows of A (the gathered matrix)
 int gemm(const Ctx &ctx, const int64_t *m, const float *A, int64_t n_src, const int32_t *gather, const float *B,
-         const float *bias, int Cin, int Cout, float *out, const int32_t *scatter, void *st) {
+         const float *bias, int Cin, int Cout, float *out, const int32_t *scatter, void *st,
+         const InBnArgs *in_bn = nullptr) {
     if (ctx.dry) return 0;
     GemmRec rec{nullptr, nullptr, 0, 0};
     if (g_timing) {
@@ -248,8 +286,11 @@ int gemm(const Ctx &ctx, const int64_t *m, const float *A, int64_t n_src, const 
         rec.bytes = 4.0 * (src * Cin + rows * Cout + (double)m[TM_K] * Cin * Cout) + 4.0 * rows;
         LIDOG_CHECK_HIP(hipEventRecord(rec.e0, (hipStream_t)st));
     }
-    int rc = lidog_sconv_gemm(A, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2), (int32_t)m[TM_NTILES],
-                              Cin, Cout, out, scatter, st);
+    int rc = in_bn ? lidog_sconv_gemm_in_bn(in_bn->pre, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2),
+                                            (int32_t)m[TM_NTILES], Cin, Cout, out, scatter, in_bn->mean, in_bn->invstd,
+                                            in_bn->w, in_bn->b, 1, st)
+                   : lidog_sconv_gemm(A, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2),
+                                      (int32_t)m[TM_NTILES], Cin, Cout, out, scatter, st);
     if (rc) return rc;
     if (g_timing) {
         LIDOG_CHECK_HIP(hipEventRecord(rec.e1, (hipStream_t)st));
@@ -303,6 +344,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
     // statistics of conv1 and of its 1x1 downsample convolution (both read the block input) in ONE message
     // (me.BasicBlock._forward_joint_sync).
     struct Pending {
+        int o;
         const int64_t *op, *c;
         float *pre, *mean, *invstd, *y;
         uint32_t *bits;
@@ -312,6 +354,8 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         float eps, mom;
     };
     const bool sync = dp.sync_bn();
+    // buffers whose BatchNorm + ReLU is applied by their reader (fusion 4): filled when the producer has run
+    std::vector<InBnArgs> lazy(n_bufs, InBnArgs{nullptr, nullptr, nullptr, nullptr, nullptr});
     // sums_at: where this layer's (sum x, sum x^2, rows) go when they are part of a joint message, else NULL
     auto conv_part = [&](int o, double *sums_at, Pending &pd) -> int {
         const int64_t *op = ops + (int64_t)o * TO_COLS;
@@ -321,6 +365,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         const int kind = (int)c[TC_KIND], Cin = (int)c[TC_CIN], Cout = (int)c[TC_COUT], K = (int)c[TC_K];
         const bool bn = op[TO_TYPE] == OP_CONVBN;
         const float *x = bp[op[TO_IN]];
+        const InBnArgs *in_bn = lazy[op[TO_IN]].pre ? &lazy[op[TO_IN]] : nullptr;   // 3^3 convolution + BatchNorm only
         const int64_t n = ctx.rows((int)op[TO_OUT]);
         const float *W = P<const float>(c[TC_W]), *bias = P<const float>(c[TC_BIAS]);
         float *y = bp[op[TO_OUT]];
@@ -355,6 +400,12 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                         Cin % 32 == 0 && Cout % 32 == 0 && lidog_get_sparse_core() == 1;
         if (os && bn) {
             double *ws = (double *)sc.take(lidog_sconv_os_stats_ws(n, Cout) * 8);
+            if (in_bn)
+                TRY(lidog_sconv_os_stats_in_bn(in_bn->pre, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
+                                               P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, bias, Cin,
+                                               Cout, pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv,
+                                               in_bn->mean, in_bn->invstd, in_bn->w, in_bn->b, 1, stream));
+            else
             TRY(lidog_sconv_os_stats(x, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
                                      P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, bias, Cin, Cout,
                                      pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
@@ -370,7 +421,8 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         } else if (kind == KIND_K3 || kind == KIND_DOWN) {
             // gathered GEMM into product rows, per-row reduction (+ BatchNorm statistics in its epilogue)
             float *T = (float *)sc.take(m[TM_P] * Cout * 4);
-            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T, nullptr, stream))
+            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T,
+                              nullptr, stream, kind == KIND_K3 ? in_bn : nullptr))
                 return rc;
             const int32_t *rp = P<const int32_t>(m[TM_RP_OUT]), *rl = P<const int32_t>(m[TM_RL_OUT]);
             if (bn) {
@@ -400,12 +452,21 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
             TRY(lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
         }
-        pd = Pending{op, c, pre, mean, invstd, y, bits, sums, n, Cout, eps, mom};
+        pd = Pending{o, op, c, pre, mean, invstd, y, bits, sums, n, Cout, eps, mom};
         return 0;
     };
     auto bn_part = [&](const Pending &pd) -> int {
         const int64_t *op = pd.op, *c = pd.c;
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
+        if (in_bn_reader(ctx, pd.o) >= 0) {
+            // no apply pass: the one reader of this output normalises the raw rows as it gathers them.  SyncBatchNorm:
+            // mean / invstd / running statistics from the all-reduced sums (the apply pass would have derived them)
+            if (sync)
+                TRY(lidog_bn_finalize(pd.sums, -1.0, pd.Cout, pd.eps, pd.mom, pd.mean, pd.invstd, P<float>(c[TC_BNRM]),
+                                      P<float>(c[TC_BNRV]), stream));
+            lazy[op[TO_OUT]] = InBnArgs{pd.pre, pd.mean, pd.invstd, P<const float>(c[TC_BNW]), P<const float>(c[TC_BNB])};
+            return 0;
+        }
         if (sync) {   // mean / invstd / running statistics from the all-reduced sums (global count behind them) + the apply
                       // pass, one launch
             TRY(lidog_bn_apply_sync(pd.pre, pd.n, pd.Cout, pd.sums, pd.eps, pd.mom, pd.mean, pd.invstd,
@@ -618,6 +679,20 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
         }
         // ---- convolution backward (me._SparseConvFn.backward)
         const float *x = bp[in_b];
+        // input normalised on the fly in the forward pass (fusion 4): the weight gradient does the same from the
+        // producer's raw output
+        InBnArgs in_bn{nullptr, nullptr, nullptr, nullptr, nullptr};
+        {
+            const int po = producer[in_b];
+            if (po >= 0 && in_bn_reader(ctx, po) == o) {
+                const int64_t *pc = convs + ops[(int64_t)po * TO_COLS + TO_CONV] * TC_COLS;
+                const int64_t *pr = rec + (int64_t)po * REC_COLS;
+                in_bn = InBnArgs{ctx.dry ? (const float *)(uintptr_t)4096 : (const float *)((char *)arena + pr[REC_PRE]),
+                                 ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_MEAN]),
+                                 ctx.dry ? nullptr : (const float *)((char *)arena + pr[REC_INVSTD]),
+                                 P<const float>(pc[TC_BNW]), P<const float>(pc[TC_BNB])};
+            }
+        }
         const int32_t *g_in, *g_out;
         if (kind == KIND_1X1) {
             g_in = g_out = P<const int32_t>(m[TM_IDENT]);
@@ -649,6 +724,11 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             } else {
                 partial = (float *)sc.take(pbytes);
             }
+            if (in_bn.pre)
+                TRY(lidog_sconv_wgrad_in_bn(in_bn.pre, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
+                                            P<const int32_t>(c[TC_ITEMOFF]), K, Cin, Cout, partial, P<float>(c[TC_GW]),
+                                            in_bn.mean, in_bn.invstd, in_bn.w, in_bn.b, 1, st));
+            else
             TRY(lidog_sconv_wgrad(x, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
                                   P<const int32_t>(c[TC_ITEMOFF]), K, Cin, Cout, partial, P<float>(c[TC_GW]), st));
             if (g_timing && !ctx.dry && Cin % 32 == 0 && Cout % 32 == 0) {

@@ -44,8 +44,10 @@ def set_enabled(on):
 
 
 def set_fusions(mask):
-    """which fusions the executor applies on top of the operator path's launch sequence (lidog_trunk_fusions; bit 1 =
-    BatchNorm-backward statistics inside the producing data-gradient reduction); returns the previous mask"""
+    """which fusions the executor applies on top of the operator path's launch sequence (lidog_trunk_fusions; 1 =
+    BatchNorm-backward statistics inside the producing data-gradient reduction, 2 = ReLU masks of the residual layers as
+    bits, 4 = the BatchNorm + ReLU between the two convolutions of a block applied in the second one's staging); returns
+    the previous mask"""
     return _lib.load().lidog_trunk_fusions(int(mask))
 
 

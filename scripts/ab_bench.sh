@@ -1,12 +1,12 @@
 #!/bin/bash
 # A/B runs of bench.py under different environments: scripts/ab_bench.sh <tag> <steps> "ENV1=.. ENV2=.." "ENV=.." ...
-# ("-" = no extra environment).  One JSON line per run in gpurun_out/ab_<tag>.log, summarised at the end.
+# (AB_ARGS="--batch 2" adds bench arguments; "-" = no extra environment).  One JSON line per run in gpurun_out/ab_<tag>.log, summarised at the end.
 tag=$1; steps=$2; shift 2
 out=gpurun_out/ab_$tag.log; : > $out
 for rep in 1 2; do
   for envs in "$@"; do
     [ "$envs" = "-" ] && envs=""
-    line=$(env $envs python bench.py --no-cpu-baseline --steps $steps 2>/dev/null | grep '^{' | tail -1)
+    line=$(env $envs python bench.py --no-cpu-baseline --steps $steps $AB_ARGS 2>/dev/null | grep '^{' | tail -1)
     echo "{\"env\": \"$envs\", \"rep\": $rep, \"res\": ${line:-null}}" >> $out
   done
 done

@@ -45,13 +45,15 @@ def _assert_same(a, b, what):
             assert torch.equal(a[k], b[k]), f"{what} {k}: max |diff| {(a[k] - b[k]).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("fusions,os_mode", [(3, 1), (1, 1), (0, 1), (3, 2), (0, 2)],
-                         ids=["fused", "bwdstats_only", "plain_sequence", "fused_output_stationary", "plain_output_stationary"])
+@pytest.mark.parametrize("fusions,os_mode", [(7, 1), (3, 1), (1, 1), (4, 1), (0, 1), (7, 2), (0, 2)],
+                         ids=["fused", "no_input_bn_fold", "bwdstats_only", "input_bn_fold_only", "plain_sequence",
+                              "fused_output_stationary", "plain_output_stationary"])
 @pytest.mark.parametrize("overlap", [True, False])
 def test_executor_step_is_bit_identical_to_the_operator_path(overlap, fusions, os_mode, monkeypatch):
     """3 optimiser steps of the LiDOG step (Adam on flat buffers), executor on vs off; with the executor's fusions
     (BatchNorm-backward statistics in the epilogue of the producing data-gradient reduction, ReLU masks of the residual
-    layers as bits) and without them; os_mode 2: every symmetric 3^3 map takes the output-stationary convolution
+    layers as bits, the BatchNorm + ReLU between the two convolutions of a block applied in the second one's staging) and
+    without them; os_mode 2: every symmetric 3^3 map takes the output-stationary convolution
     (csrc/sconv_os.hip; by default only maps of >= 1500 tiles do, which these scenes are not)"""
     from lidog_amd import me as ME, trunk
     from lidog_amd.trainer import LiDOGStep
