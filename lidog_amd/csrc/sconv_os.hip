@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                                                        const float *__restrict__ W, int reverse,
                                                        const float *__restrict__ bias,
                                                        const float *__restrict__ addend, int Cin, int Cout,
-                                                       float *__restrict__ out, OsStats st, InBn in_bn) {
+                                                       float *__restrict__ out, OsStats st, InBn in_bn, int xcd_group) {
     constexpr int TN = 32 * NT;
     constexpr int BV = (OS_BK * TN / 4) / 256;
     __shared__ float As[OS_TM * OS_SA];
@@ -299,7 +299,18 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
     __shared__ int32_t s_row[OS_TM];
     __shared__ int32_t s_nbr[OS_MAXK * OS_TM];   // neighbour row of (offset, tile row), -1 = none
 
-    const int tile = tile_order[blockIdx.x];   // heaviest tiles first
+    // heaviest tiles first; with xcd_group > 0 runs of that many consecutive tiles of the order (neighbouring rows of one
+    // mask class: they gather overlapping sets of input rows) land on the same XCD and its L2 (workgroups go to the 8
+    // XCDs round-robin)
+    int slot = blockIdx.x;
+    if (xcd_group > 0) {
+        const int per_round = 8 * xcd_group, full = ((int)gridDim.x / per_round) * per_round;
+        if (slot < full) {
+            const int xcd = slot & 7, j = slot >> 3;
+            slot = ((j / xcd_group) * 8 + xcd) * xcd_group + j % xcd_group;
+        }
+    }
+    const int tile = tile_order[slot];
     const int col0 = blockIdx.y * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
@@ -480,9 +491,17 @@ static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const
     }
     if (force_nt >= 1 && force_nt <= 4 && Cout % (32 * force_nt) == 0) nt = force_nt;
     dim3 grid((unsigned)(os_pad(n) / OS_TM), (unsigned)(Cout / (32 * nt)));
+    // runs of 4 consecutive tiles of the launch order per XCD (measured in the step, same box, alternating: 48.13 / 48.07 ->
+    // 48.07 / 47.99 ms; 2: 48.11 / 47.95; 8: 48.14 / 48.20; 16: 48.23 / 48.35; 64: 50.3 -- the heaviest-first order must
+    // survive); LIDOG_OS_XCD_GROUP=0: plain round-robin
+    static int xcd_group = -1;
+    if (xcd_group < 0) {
+        const char *e = getenv("LIDOG_OS_XCD_GROUP");
+        xcd_group = e ? atoi(e) : 4;
+    }
 #define OS_LAUNCHF(NT_, MW_, F_)                                                                                 \
     k_sconv_os_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, \
-                                                        addend, Cin, Cout, out, stats, in_bn)
+                                                        addend, Cin, Cout, out, stats, in_bn, xcd_group)
 #define OS_LAUNCH(NT_, MW_) OS_LAUNCHF(NT_, MW_, false)
     if (in_bn.mean) {   // 16 more registers: the 64-column kernel no longer fits four waves per SIMD
         switch (nt) {
