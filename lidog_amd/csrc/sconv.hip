@@ -1037,18 +1037,28 @@ __global__ __launch_bounds__(256) void k_sconv_wgrad_cin1(const float *__restric
     const int item = blockIdx.x;
     const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
     const int c = threadIdx.x % Cout, r = threadIdx.x / Cout, RL = 256 / Cout;
-    float acc0 = 0.f, acc1 = 0.f;
+    // eight pairs per round and thread, their (dependent) index -> value loads all in flight together: this launch is the
+    // last one of the backward pass (the stem's output gradient is the last thing the main stream produces) and the
+    // optimiser waits for it -- 172 -> 95 us (two pairs per round before).  Pairs past the end are clamped to the last
+    // one and contribute a * 0.
+    constexpr int U = 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (r < RL) {
-        int64_t p = p0 + r;
-        for (; p + RL < p1; p += 2 * RL) {
-            float a0 = A[pa[p]], a1 = A[pa[p + RL]];
-            float g0 = G[(size_t)pg[p] * Cout + c], g1 = G[(size_t)pg[p + RL] * Cout + c];
-            acc0 = __builtin_fmaf(a0, g0, acc0);
-            acc1 = __builtin_fmaf(a1, g1, acc1);
+        for (int64_t p = p0 + r; p < p1; p += U * RL) {
+            float a[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t pu = p + (int64_t)u * RL;
+                const int64_t pc = pu < p1 ? pu : p1 - 1;
+                a[u] = A[pa[pc]];
+                g[u] = G[(size_t)pg[pc] * Cout + c];
+                if (pu >= p1) a[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u & 3] = __builtin_fmaf(a[u], g[u], acc[u & 3]);
         }
-        if (p < p1) acc0 = __builtin_fmaf(A[pa[p]], G[(size_t)pg[p] * Cout + c], acc0);
     }
-    red[threadIdx.x] = acc0 + acc1;
+    red[threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
     if (r == 0) {
         float s = red[c];
