@@ -23,3 +23,7 @@ struct IgParams {
 enum { IG_FWD = 0, IG_DGRAD = 1, IG_WGRAD = 2 };
 
 #define C2_KB 32  // reduction depth of one LDS stage (FWD / DGRAD)
+
+// Wd = the data-gradient weight slabs of the four stride-2 parity classes of a 3x3 kernel W [Cout][Cin][3][3], in class
+// order (9 Cin Cout floats), one launch (conv2d.hip)
+void lidog_launch_repack_dgrad_all(const float *W, int Cin, int Cout, float *Wd, hipStream_t st);

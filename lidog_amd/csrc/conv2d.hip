@@ -350,19 +350,30 @@ __global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
 }
 
 // ------------------------------------------------------------------ weight repack for DGRAD
-// Wd[ci][co*nt + tap] = W[co][ci][ky(tap)][kx(tap)] for one parity class
-__global__ __launch_bounds__(256) void k_repack_dgrad(const float *__restrict__ W, int Cin, int Cout, int nky,
-                                                      int nkx, int ky0, int kystep, int kx0, int kxstep,
-                                                      float *__restrict__ Wd) {
-    int nt = nky * nkx;
-    int64_t total = (int64_t)Cin * Cout * nt;
+// Wd[ci][co*nt + tap] = W[co][ci][ky(tap)][kx(tap)] per parity class;
+// all four parity classes (py, px) in one launch: class cls = 2 py + px owns nt = (py ? 2 : 1) (px ? 2 : 1) taps and the
+// slab behind the classes before it (Cin * Cout * {0, 1, 3, 5} floats) -- four launches of a few microseconds each sat
+// between the data-gradient kernels of every 3x3 convolution
+__global__ __launch_bounds__(256) void k_repack_dgrad_all(const float *__restrict__ W, int Cin, int Cout,
+                                                          float *__restrict__ Wd) {
+    const int64_t cc = (int64_t)Cin * Cout;
     int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    int kd = (int)(e % ((int64_t)Cout * nt));
-    int ci = (int)(e / ((int64_t)Cout * nt));
+    if (e >= 9 * cc) return;
+    const int cls = e < cc ? 0 : e < 3 * cc ? 1 : e < 5 * cc ? 2 : 3;
+    const int64_t base = cls == 0 ? 0 : cls == 1 ? cc : cls == 2 ? 3 * cc : 5 * cc;
+    const int py = cls >> 1, px = cls & 1;
+    const int nky = py ? 2 : 1, nkx = px ? 2 : 1, ky0 = py ? 0 : 1, kx0 = px ? 0 : 1, nt = nky * nkx;
+    const int64_t l = e - base;
+    int kd = (int)(l % ((int64_t)Cout * nt));
+    int ci = (int)(l / ((int64_t)Cout * nt));
     int co = kd / nt, tap = kd % nt;
-    int ky = ky0 + (tap / nkx) * kystep, kx = kx0 + (tap % nkx) * kxstep;
+    int ky = ky0 + (tap / nkx) * 2, kx = kx0 + (tap % nkx) * 2;
     Wd[e] = W[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+}
+
+void lidog_launch_repack_dgrad_all(const float *W, int Cin, int Cout, float *Wd, hipStream_t st) {
+    const int64_t total = 9 * (int64_t)Cin * Cout;
+    k_repack_dgrad_all<<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(W, Cin, Cout, Wd);
 }
 
 __global__ __launch_bounds__(256) void k_sum_splits(const float *__restrict__ partial, int64_t n, int splits,
@@ -508,6 +519,7 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
                   "conv2d_dgrad: tensor too large for 32-bit offsets / reduction table");
     int Ho = out_dim(H, 3, 2, 1), Wo = out_dim(W, 3, 2, 1);
     float *slab = ws;
+    lidog_launch_repack_dgrad_all(w, Cin, Cout, ws, st);
     for (int py = 0; py < 2; ++py) {
         for (int px = 0; px < 2; ++px) {
             IgParams p = {};
@@ -521,8 +533,6 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
             int nt = p.nky * p.nkx;
             p.Mi = Cin; p.Nj = B * p.Hc * p.Wc; p.Kd = Cout * nt;
             int64_t total = (int64_t)Cin * Cout * nt;
-            k_repack_dgrad<<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(w, Cin, Cout, p.nky, p.nkx, p.ky0, p.kystep,
-                                                                         p.kx0, p.kxstep, slab);
             p.A = slab;
             slab += total;
             if (p.Nj > 0) {

@@ -41,10 +41,10 @@ struct ListGeom {
 };
 
 // lists[tile][0] = number of active channels, lists[tile][1..] = their ids, ascending
-__global__ __launch_bounds__(128) void k_tile_lists(const uint64_t *__restrict__ bits, int words, ListGeom g,
-                                                    int32_t *__restrict__ lists, uint64_t *__restrict__ tbits) {
+__device__ __forceinline__ void tile_list(const uint64_t *__restrict__ bits, int words, const ListGeom &g,
+                                          int32_t *__restrict__ lists, uint64_t *__restrict__ tbits, int tile) {
     __shared__ int s_cnt[2];
-    const int c = threadIdx.x, tile = blockIdx.x;
+    const int c = threadIdx.x;
     int j = tile * IG_T;
     const int j1 = (j + IG_T - 1 < g.Nj - 1) ? j + IG_T - 1 : g.Nj - 1;
     const int hw = g.Hc * g.Wc;
@@ -81,6 +81,26 @@ __global__ __launch_bounds__(128) void k_tile_lists(const uint64_t *__restrict__
     if (act) lst[1 + (wv ? s_cnt[0] : 0) + pre] = c;
     if (c == 0) lst[0] = s_cnt[0] + s_cnt[1];
     if (tbits && lane == 0) tbits[(size_t)tile * 2 + wv] = bal;  // bit c of the tile's 128-bit channel mask
+}
+
+__global__ __launch_bounds__(128) void k_tile_lists(const uint64_t *__restrict__ bits, int words, ListGeom g,
+                                                    int32_t *__restrict__ lists, uint64_t *__restrict__ tbits) {
+    tile_list(bits, words, g, lists, tbits, (int)blockIdx.x);
+}
+
+// the four data-gradient classes in one launch (they feed the backward pass only, but are built on the forward pass's
+// stream: four launches of ~870 workgroups each cost four launch latencies there): workgroup x belongs to the class
+// whose tile range [first[cls], first[cls + 1]) holds it
+struct ListGeom4 {
+    ListGeom g[4];
+    int first[5];
+    int64_t off[4];
+};
+__global__ __launch_bounds__(128) void k_tile_lists4(const uint64_t *__restrict__ bits, int words, ListGeom4 q,
+                                                     int32_t *__restrict__ act) {
+    const int x = blockIdx.x;
+    const int cls = x < q.first[1] ? 0 : x < q.first[2] ? 1 : x < q.first[3] ? 2 : 3;
+    tile_list(bits, words, q.g[cls], act + q.off[cls], nullptr, x - q.first[cls]);
 }
 
 // Weight gradient: the columns (ci, tap) of gW are cut into groups of WA_GC channels; group g works on the pixel
@@ -171,15 +191,18 @@ extern "C" int lidog_conv2d_support(const int32_t *support, int32_t B, int32_t C
     uint64_t *tbits = reinterpret_cast<uint64_t *>(act + L.tbits_off);
     k_tile_lists<<<(unsigned)L.fwd_tiles, 128, 0, st>>>(bits, L.words, g, act + L.fwd_off, tbits);
     k_group_lists<<<(unsigned)L.groups, 256, 0, st>>>(tbits, L.fwd_tiles, Cin, act + L.glists_off);
+    ListGeom4 q;
+    q.first[0] = 0;
     for (int cls = 0; cls < 4; ++cls) {
         int py = cls >> 1, px = cls & 1;
         g.Hc = (H - py + 1) / 2; g.Wc = (W - px + 1) / 2; g.Nj = B * g.Hc * g.Wc;
         g.ya = py; g.ny = 1; g.xlo = px; g.xhi = px;
         g.mask = px ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
-        if (L.dgrad_tiles[cls] > 0)
-            k_tile_lists<<<(unsigned)L.dgrad_tiles[cls], 128, 0, st>>>(bits, L.words, g, act + L.dgrad_off[cls],
-                                                                       nullptr);
+        q.g[cls] = g;
+        q.off[cls] = L.dgrad_off[cls];
+        q.first[cls + 1] = q.first[cls] + L.dgrad_tiles[cls];
     }
+    if (q.first[4] > 0) k_tile_lists4<<<(unsigned)q.first[4], 128, 0, st>>>(bits, L.words, q, act);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -492,20 +515,6 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_act(IgParams p, const int32_
     else conv_dgrad_act_body<4>(p, s_ch, n_act, As, Bs, s_tab);
 }
 
-__global__ __launch_bounds__(256) void k_repack_dgrad2(const float *__restrict__ W, int Cin, int Cout, int nky,
-                                                       int nkx, int ky0, int kystep, int kx0, int kxstep,
-                                                       float *__restrict__ Wd) {
-    int nt = nky * nkx;
-    int64_t total = (int64_t)Cin * Cout * nt;
-    int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    int kd = (int)(e % ((int64_t)Cout * nt));
-    int ci = (int)(e / ((int64_t)Cout * nt));
-    int co = kd / nt, tap = kd % nt;
-    int ky = ky0 + (tap / nkx) * kystep, kx = kx0 + (tap % nkx) * kxstep;
-    Wd[e] = W[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
-}
-
 extern "C" int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const int32_t *act, int32_t B, int32_t Cin,
                                          int32_t H, int32_t W, int32_t Cout, float *gx, float *ws, void *stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -517,6 +526,7 @@ extern "C" int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const 
                   "conv2d_dgrad_sparse: tensor too large for 32-bit offsets / reduction table");
     ActLayout L = act_layout(B, Cin, H, W);
     float *slab = ws;
+    lidog_launch_repack_dgrad_all(w, Cin, Cout, ws, st);   // conv2d.hip: the four classes' weight slabs, one launch
     for (int cls = 0; cls < 4; ++cls) {
         int py = cls >> 1, px = cls & 1;
         IgParams p = {};
@@ -529,8 +539,6 @@ extern "C" int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const 
         int nt = p.nky * p.nkx;
         p.Mi = Cin; p.Nj = B * p.Hc * p.Wc; p.Kd = Cout * nt;
         int64_t total = (int64_t)Cin * Cout * nt;
-        k_repack_dgrad2<<<(unsigned)cdiv64(total, 256), 256, 0, st>>>(w, Cin, Cout, p.nky, p.nkx, p.ky0, p.kystep,
-                                                                      p.kx0, p.kxstep, slab);
         p.A = slab;
         slab += total;
         if (p.Nj > 0)
