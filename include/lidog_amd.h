@@ -547,6 +547,10 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
  * weight-gradient stream of the backward pass off part of the chip (lidog_amd.me._WgradLane, LIDOG_LANE_CU_MASK) */
 int lidog_stream_create_cu_mask(const uint32_t *mask, int32_t words, void **stream_out);
 int32_t lidog_trunk_fusions(int32_t mask);
+/* readers [n_ops]: which op (a 3^3 convolution + BatchNorm) applies op o's BatchNorm + ReLU in its staging under fusion 4,
+ * -1 where the BatchNorm keeps its own pass -- conv1 of every BasicBlock in MinkUNet34.  Host only (tables as above). */
+int lidog_trunk_in_bn_readers(const int64_t *convs, int32_t n_convs, const int64_t *maps, int32_t n_maps,
+                              const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs, int32_t *readers);
 /* Timing of the executor's gathered-GEMM launches for the roofline figure of bench.py: on != 0 brackets every such
  * launch with HIP events on its stream; _read waits for the recorded launches, returns (launches, total ms, algorithmic
  * FLOPs, algorithmic bytes: SURVEY.md 8(d)) in out[0..3] and forgets them.  One timing client per process. */

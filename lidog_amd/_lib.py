@@ -119,6 +119,7 @@ SIGNATURES = {
     "lidog_stream_create_cu_mask": [_p, _i32, ctypes.POINTER(ctypes.c_void_p)],
     "lidog_bn_apply_sync": [_p, _i64, _i32, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "lidog_trunk_fusions": [_i32],
+    "lidog_trunk_in_bn_readers": [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _p],
     "lidog_trunk_gemm_timing": [_i32],
     "lidog_trunk_gemm_timing_read": [_p],
     "lidog_trunk_work_read": [_p],

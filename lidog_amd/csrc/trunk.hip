@@ -873,6 +873,17 @@ extern "C" int lidog_stream_create_cu_mask(const uint32_t *mask, int32_t words, 
     return 0;
 }
 
+// readers [n_ops]: for every op the op index of the convolution that normalises its output while staging it (fusion 4,
+// in_bn_reader above), -1 where the BatchNorm keeps its own apply pass.  Host only; what the two passes will decide.
+extern "C" int lidog_trunk_in_bn_readers(const int64_t *convs, int32_t n_convs, const int64_t *maps, int32_t n_maps,
+                                         const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs,
+                                         int32_t *readers) {
+    LIDOG_REQUIRE(convs && maps && ops && bufs && readers, "trunk_in_bn_readers: null argument");
+    Ctx ctx{convs, nullptr, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, nullptr, nullptr, true};
+    for (int o = 0; o < n_ops; ++o) readers[o] = in_bn_reader(ctx, o);
+    return 0;
+}
+
 // Which fusions the executor applies (bit mask, see g_fusions; default: all).  Returns the previous mask; < 0 only reads.
 extern "C" int32_t lidog_trunk_fusions(int32_t mask) {
     int32_t old = g_fusions;

@@ -109,6 +109,39 @@ def test_dry_run_plans_memory_and_gradient_reach(prog):
     assert not done.any()
 
 
+def test_batchnorms_applied_in_their_readers_staging_are_conv1_of_every_block(prog):
+    """fusion 4 of the executor (csrc/trunk.hip:in_bn_reader): a BatchNorm + ReLU loses its apply pass exactly when its
+    output has one reader and that reader is a 3^3 convolution + BatchNorm with channel counts in multiples of 32 -- in
+    MinkUNet34 conv1 -> norm1 -> relu -> conv2 of the 23 BasicBlocks and nothing else (not the stem or the strided
+    convolutions, whose outputs a block reads twice, not the block outputs, not the transposed convolutions that feed a
+    concatenation)"""
+    from lidog_amd import _lib, trunk
+    L = _lib.load()
+    maps, convs, _ = _tables(prog, [20000, 12000, 6000, 2500, 900])
+    ops = prog.ops
+    readers = np.full(len(ops), -2, np.int32)
+    before = L.lidog_trunk_fusions(7)
+    try:
+        rc = L.lidog_trunk_in_bn_readers(convs.ctypes.data, len(convs), maps.ctypes.data, len(maps), ops.ctypes.data, len(ops),
+                                         prog.bufs.ctypes.data, len(prog.bufs), readers.ctypes.data)
+        assert rc == 0, L.lidog_last_error()
+        folded = np.nonzero(readers >= 0)[0]
+        assert len(folded) == 23
+        for o in folded:
+            r = readers[o]
+            assert r == o + 1 or r == o + 2                       # conv2 follows conv1, a downsample branch may sit between
+            assert ops[o, 0] == trunk.OP_CONVBN and ops[o, 4] == 1 and ops[o, 5] < 0          # BatchNorm + ReLU, no residual
+            assert ops[r, 0] == trunk.OP_CONVBN and ops[r, 2] == ops[o, 3] and ops[r, 5] >= 0  # reads it; adds the residual
+            c1, c2 = convs[ops[o, 1]], convs[ops[r, 1]]
+            assert c1[0] == c2[0] == trunk.KIND_K3 and c2[2] == c2[3] == c1[3] and c1[3] % 32 == 0
+        L.lidog_trunk_fusions(3)                                    # switched off: nobody
+        L.lidog_trunk_in_bn_readers(convs.ctypes.data, len(convs), maps.ctypes.data, len(maps), ops.ctypes.data, len(ops),
+                                    prog.bufs.ctypes.data, len(prog.bufs), readers.ctypes.data)
+        assert (readers == -1).all()
+    finally:
+        L.lidog_trunk_fusions(before)
+
+
 def test_data_parallel_descriptor_is_checked_and_planned(prog):
     """dp argument of the executor (include/lidog_amd.h): SyncBatchNorm without a communicator or callback, and bucket
     tables without a transport, are refused; a dry run with SyncBatchNorm on plans the same regions (the joint
