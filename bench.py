@@ -108,6 +108,106 @@ class GemmTimer:
         return dict(launches=n, total_ms=ms, bytes=by, flops=fl)
 
 
+def usable_cpus():
+    """(cpus this process may really use, how that was found): the scheduler affinity, cut by the cgroup CPU quota when
+    one is set -- a GPU box hands a one-GPU job a share of the host's threads, os.cpu_count() still says the whole host"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    how = f"affinity {n}"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = float(quota) / period
+                how += f", cgroup quota {q:.1f}"
+                n = max(1, min(n, int(q + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, how
+
+
+def _cpu_model(config):
+    import oracle.me_cpu as OME
+    from oracle.ref_torch import Encoder2DRef, sparse2super_ref
+    from lidog_amd.minkunet import make_models
+    torch.manual_seed(0)
+    cls = make_models(OME, Encoder2DRef, lambda x, bound, voxel, pool: sparse2super_ref(x.C, x.F, bound, voxel, pool))
+    model = cls.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"],
+                              mapping_bound_2d=50.0)
+    model.train()
+    return model, torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+
+def cpu_worker(config, threads, first_seed, steps):
+    """one worker process of the whole-host CPU leg (`python bench.py --cpu-worker ...`, never touches the GPU): the
+    oracle's training step on `steps` scans after one untimed step; prints {"steps", "seconds"}"""
+    import oracle.me_cpu as OME
+    from oracle.ref_torch import soft_dice_loss_ref, dice_loss_ref
+    from oracle.me_cpu._lib import lib as _olib
+    from lidog_amd import synth
+    OME.set_mode("blas")
+    torch.set_num_threads(threads)
+    _olib().orc_set_threads(threads)
+    model, opt = _cpu_model(config)
+    scans = [synth.make_batch([first_seed + i], config, device="cpu") for i in range(steps + 1)]
+
+    def one_step(b):
+        st = OME.SparseTensor(coordinates=b["coords_int"], features=b["source_features0"])
+        sem, bev = model(st, is_train=True)
+        loss = 0.5 * soft_dice_loss_ref(sem.F, b["source_sem_labels0"]) + \
+            0.5 * dice_loss_ref(bev["block8"].view(-1, 7), b["source_bev_labels0"]["block8"].view(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    one_step(scans[0])
+    t0 = time.time()
+    for b in scans[1:]:
+        one_step(b)
+    print(json.dumps({"steps": steps, "seconds": time.time() - t0, "t0": t0, "t1": time.time()}), flush=True)
+
+
+def cpu_whole_host(config, threads_per_worker, single):
+    """cpu_baseline.whole_host (north_star: "timed on the same box's host cores"): floor(usable cpus / threads) worker
+    PROCESSES x `threads_per_worker` threads, each running the oracle's training step on its own scans, all at once; the
+    figure is the sum of the workers' scans/s.  Workers are fresh children (`--cpu-worker`) started by a process that may
+    hold the GPU: they never touch it.  With one worker's worth of cpus the single-process figure IS the whole-host one."""
+    import subprocess
+    ncpu, how = usable_cpus()
+    forced = os.environ.get("LIDOG_CPU_BASELINE_WORKERS")
+    workers = int(forced) if forced else max(1, ncpu // threads_per_worker)
+    workers = min(workers, 32)
+    out = {"usable_cpus": ncpu, "usable_cpus_source": how, "host_cpu_count": os.cpu_count(),
+           "threads_per_worker": threads_per_worker, "workers": workers, "unit": "scans/s"}
+    if workers == 1:
+        out.update(value=single, cores=threads_per_worker, same_as_single_process=True,
+                   sample="one worker's worth of usable cpus: the single-process figure above is the whole-host figure")
+        return out
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads_per_worker), MKL_NUM_THREADS=str(threads_per_worker),
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", config,
+                               str(threads_per_worker), str(100 + 10 * w), "2"],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for w in range(workers)]
+    rates, spans = [], []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+            d = json.loads([l for l in o.splitlines() if l.startswith("{")][-1])
+            rates.append(d["steps"] / d["seconds"])
+            spans.append((d["t0"], d["t1"]))
+        except Exception:       # a worker that died (memory) is simply not counted, and said so
+            p.kill()
+    overlap = (min(t1 for _, t1 in spans) - max(t0 for t0, _ in spans)) / max(t1 - t0 for t0, t1 in spans) if spans else 0.0
+    out.update(value=sum(rates), cores=threads_per_worker * len(rates), workers_finished=len(rates),
+               per_worker_scans_per_s=[round(r, 4) for r in rates], timed_windows_overlap=round(overlap, 3),
+               sample=f"{len(rates)} of {workers} worker processes x {threads_per_worker} threads, 2 training steps each on own "
+                      f"scans after one untimed step, oracle blas mode, started together; value = sum of the workers' rates")
+    return out
+
+
 def cpu_baseline(config, steps_budget_s=14.0, threads=None):
     """The CPU oracle (ME-equivalent restatement, per-offset gather -> BLAS GEMM -> scatter-add) timed on this box's
     host cores on a BOUNDED sample of the same workload: the headline configuration's training step and
@@ -126,12 +226,7 @@ def cpu_baseline(config, steps_budget_s=14.0, threads=None):
         torch.set_num_threads(n)
         _olib().orc_set_threads(n)
 
-    torch.manual_seed(0)
-    cls = make_models(OME, Encoder2DRef, lambda x, bound, voxel, pool: sparse2super_ref(x.C, x.F, bound, voxel, pool))
-    model = cls.MinkUNet34BEV(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"],
-                              mapping_bound_2d=50.0)
-    model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    model, opt = _cpu_model(config)
     scans = [synth.make_batch([seed], config, device="cpu") for seed in (0, 1, 2)]
 
     def forward_only(b):
@@ -216,7 +311,11 @@ def cpu_baseline(config, steps_budget_s=14.0, threads=None):
         c1 = {"error": repr(e)}
     OME.set_mode("exact")
     torch.set_num_threads(prev_threads)
-    return {"value": n / dt, "unit": "scans/s", "cores": best, "host_cpu_count": ncpu,
+    try:
+        whole = cpu_whole_host(config, best, n / dt)
+    except Exception as e:      # the headline line must not depend on this leg
+        whole = {"error": repr(e)}
+    return {"value": n / dt, "unit": "scans/s", "cores": best, "host_cpu_count": ncpu, "whole_host": whole,
             "torch_num_threads": best, "kind": "port",
             "thread_sweep_forward_s_per_scan": sweep or None,
             "forward_only_scans_per_s": 2 / dt_f,
@@ -272,11 +371,91 @@ def launch_ranks(args):
     if timed_out[0]:
         sys.stderr.write(f"bench.py: the {args.gpus}-rank run printed nothing for {limit:.0f} s and was killed\n")
         rc = rc or 124
+    if rc == 0:
+        # phase 2: rank 0's line is out and every rank has torn down and left -- nothing below can change the result
+        probe_phase([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                     "--master-addr", "127.0.0.1", "--master-port", str(_free_port())], dict(os.environ))
     sys.exit(rc if rc >= 0 else 128 - rc)
 
 
+PROBE_SCRIPT = os.path.join(REPO, "scripts", "micro_peer_allreduce.py")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def probe_phase(prefix, env):
+    """Second, short phase of an N > 1 run, AFTER the headline line has been printed and flushed and the ranks of the
+    timed run are gone: fresh processes (`prefix` + scripts/micro_peer_allreduce.py) set up the one-shot peer all-reduce
+    in probe mode and time one 193-double statistics message through it, through this library's RCCL communicator and
+    through torch.distributed -- the path the SyncBatchNorm design rests on has never run between
+    two GPUs, and no training step may be its first run.  Own watchdog (LIDOG_BENCH_PROBE_WATCHDOG_S, at most 120 s: the
+    process group is killed), everything it prints goes to stderr, its exit code is ignored.  LIDOG_BENCH_PROBE=0 skips it."""
+    import signal
+    import subprocess
+    if os.environ.get("LIDOG_BENCH_PROBE", "1") == "0":
+        return None
+    limit = min(120.0, float(os.environ.get("LIDOG_BENCH_PROBE_WATCHDOG_S", "120")))
+    script = os.environ.get("LIDOG_BENCH_PROBE_SCRIPT", PROBE_SCRIPT)       # (override: tests)
+    env = {k: v for k, v in env.items() if k not in ("LIDOG_PEER_ALLREDUCE", "LIDOG_PEER_FAULT")}
+    try:
+        proc = subprocess.Popen(prefix + [script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env,
+                                start_new_session=True, text=True)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: peer probe not started: {e}\n")
+        return None
+    try:
+        out, _ = proc.communicate(timeout=limit)
+        code = proc.returncode
+    except subprocess.TimeoutExpired:
+        # SIGTERM first: the launcher ends its workers itself; then SIGKILL for whatever is left of the group.  Never wait
+        # for ever on the pipe (an orphaned worker could hold it open)
+        out = ""
+        for sig, wait in ((signal.SIGTERM, 15), (signal.SIGKILL, 5)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                pass
+            try:
+                out, _ = proc.communicate(timeout=wait)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        code = "killed"
+        sys.stderr.write(f"bench.py: peer probe killed after {limit:.0f} s (ignored)\n")
+    keep = [l for l in (out or "").splitlines() if "peer_probe" in l or "Error" in l or "error" in l]
+    sys.stderr.write("\n".join(keep[-20:]) + ("\n" if keep else ""))
+    sys.stderr.write(f"bench.py: peer probe finished ({code}); its exit code is ignored\n")
+    sys.stderr.flush()
+    return code
+
+
+# LIDOG_* variables that only say HOW the bench is launched (ranks, watchdog, which legs run): they do not change what
+# a step computes or which kernels it takes.  Everything else that is set is an experiment switch and is echoed in
+# `config.env`, so that a line can never silently describe another workload or another build of the step.
+_LAUNCH_ONLY_ENV = ("LIDOG_BENCH_LAUNCHED_BY_PARENT", "LIDOG_BENCH_WATCHDOG_S", "LIDOG_BENCH_RANK_SCRIPT",
+                    "LIDOG_BENCH_PROBE", "LIDOG_BENCH_PROBE_WATCHDOG_S", "LIDOG_CPU_BASELINE_THREADS",
+                    "LIDOG_CPU_BASELINE_WORKERS")
+
+
+def experiment_env():
+    """every LIDOG_* variable set in this process's environment that can change what the step runs"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("LIDOG_") and k not in _LAUNCH_ONLY_ENV}
+
+
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     args = parse()
+    headline = (args.config, args.batch) == ("kitti120k", 4)
+    if headline and os.environ.get("LIDOG_SYNTH_ROW_ORDER"):
+        # the (configs[1]) line is BASELINE.md's workload in the generator's row order; a re-ordered batch is another input
+        sys.exit("bench.py: LIDOG_SYNTH_ROW_ORDER is set: refusing to print a configs[1] line for re-ordered scans "
+                 "(use --config / --batch other than the headline's, or unset it)")
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
     rank = int(os.environ.get("RANK", 0))
@@ -496,7 +675,8 @@ def main():
                                       f"bs={args.batch}/GPU, SoftDICE+DICE, Adam",
                           "voxels_per_scan": n_vox, "seed0_stride_counts": seed0_counts,
                           "global_batch": world * args.batch,
-                          "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else "")},
+                          "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else ""),
+                          "env": experiment_env()},
                "blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in blocks], "loss": loss}
         if world > 1 or single_dp:
             from lidog_amd.comm import transport
@@ -592,7 +772,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+            wh = res["cpu_baseline"].get("whole_host") or {}
+            if wh.get("value"):
+                res["gpu_over_cpu_whole_host"] = value / wh["value"]
         print(json.dumps(res), flush=True)
+    probe_port = None
+    if world > 1 and os.environ.get("LIDOG_BENCH_LAUNCHED_BY_PARENT") != "1" and not peer_error:
+        # ranks started by somebody else's launcher (the driver's torch.distributed.run line): there is no parent of ours
+        # to run the probe phase, so every rank starts its own probe child once it has torn down; the rendezvous port of
+        # that second group is agreed while the first group still exists
+        box = [_free_port() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        probe_port = box[0]
     if world > 1 or single_dp:
         # orderly teardown: every rank has finished its collectives (barrier + synchronize), then this library's
         # communicators and mailboxes go (ncclCommDestroy, hipIpcCloseMemHandle), then torch's group -- no RCCL object is
@@ -604,6 +795,12 @@ def main():
         dist.destroy_process_group()
     if peer_error:      # every rank holds the same verdict (Transport.check is collective): all leave non-zero
         sys.exit(f"bench.py: {peer_error}")
+    if probe_port is not None:
+        # the headline line is out (printed and flushed above) and this rank holds no communicator any more; the child is a
+        # fresh process on this rank's GPU, bounded by its own watchdog, exit code ignored
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(probe_port))
+        probe_phase([sys.executable], env)
 
 
 if __name__ == "__main__":

@@ -397,6 +397,9 @@ int32_t lidog_peer_max_doubles(void *comm);
 int lidog_peer_set_spin_limit(void *comm, int64_t polls /* ~1-2 us each; 0 = default, several minutes */);
 int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void *stream);
 int32_t lidog_peer_status(void *comm);   /* 0 ok, 1 a sender's flag never arrived, 2 a sender was ahead (desynchronised) */
+/* Frees the local mailbox and (close_peers != 0) unmaps the peers'.  PRECONDITION the library cannot check: every rank
+ * has synchronised its stream and ALL ranks have passed a barrier after their last call -- a peer may otherwise still
+ * store into (or poll) this rank's mailbox through its hipIpc mapping when the memory goes away. */
 int lidog_peer_comm_destroy(void *comm, int32_t close_peers);
 /* A communicator's calls must all be queued on one stream (the mailbox slots are reused in stream order): the first
  * call binds it, a call on another stream is refused; lidog_peer_rebind_stream waits for the old stream and moves it. */

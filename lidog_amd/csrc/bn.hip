@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <map>
 #include <unordered_map>
 
 #include "common.h"
@@ -244,20 +245,39 @@ __global__ __launch_bounds__(256) void k_colreduce_strided(const float *__restri
 
 // Ticket words of the in-kernel finish (stats_tail.h): one block of 1 + STATS_MAX_GROUPS words per stream, zeroed when it
 // is created and left zeroed by every launch that used it.  Launches that share a block are ordered by their stream.
+static const size_t kTicketBytes = sizeof(unsigned) * (1 + STATS_MAX_GROUPS + 63) / 64 * 64;
+static std::map<std::pair<int, hipStream_t>, unsigned *> g_ticket_blocks;   // (device, stream): the null stream's handle
+static std::mutex g_ticket_lock;                                            // is the same on every device
+
 unsigned *lidog_stats_tickets(hipStream_t stream) {
-    static std::unordered_map<hipStream_t, unsigned *> blocks;
-    static std::mutex lock;
-    std::lock_guard<std::mutex> guard(lock);
-    auto it = blocks.find(stream);
-    if (it != blocks.end()) return it->second;
-    unsigned *p = nullptr;
-    const size_t bytes = sizeof(unsigned) * (1 + STATS_MAX_GROUPS + 63) / 64 * 64;
-    if (hipMalloc((void **)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
-        lidog_set_error("stats tickets: cannot allocate %zu bytes of device memory", bytes);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        lidog_set_error("stats tickets: no current device");
         return nullptr;
     }
-    blocks[stream] = p;
+    std::lock_guard<std::mutex> guard(g_ticket_lock);
+    const auto key = std::make_pair(dev, stream);
+    auto it = g_ticket_blocks.find(key);
+    if (it != g_ticket_blocks.end()) return it->second;
+    unsigned *p = nullptr;
+    if (hipMalloc((void **)&p, kTicketBytes) != hipSuccess || hipMemset(p, 0, kTicketBytes) != hipSuccess) {
+        lidog_set_error("stats tickets: cannot allocate %zu bytes of device memory", kTicketBytes);
+        return nullptr;
+    }
+    g_ticket_blocks[key] = p;
     return p;
+}
+
+// A launch that ended in an error may have left arrivals in the ticket words of its stream (every later launch there would
+// pick the wrong last workgroup and publish wrong sums): zero them again, in stream order.  Called by lidog_set_error's
+// users through LIDOG_LAUNCH_CHECK failures of the statistics kernels (lidog_stats_tail_finish below).
+int lidog_stats_tickets_reset(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    std::lock_guard<std::mutex> guard(g_ticket_lock);
+    auto it = g_ticket_blocks.find(std::make_pair(dev, stream));
+    if (it == g_ticket_blocks.end()) return 0;
+    return hipMemsetAsync(it->second, 0, kTicketBytes, stream) == hipSuccess ? 0 : 1;
 }
 
 int lidog_stats_tail_make(StatsTail *tail, double *partial, double *sums, double count, int C, BnFinish fin,
@@ -277,7 +297,12 @@ int lidog_stats_tail_make(StatsTail *tail, double *partial, double *sums, double
 }
 
 int lidog_stats_tail_finish(const StatsTail &tail, int nb, hipStream_t st) {
-    if (tail.tickets) return 0;
+    if (tail.tickets) {
+        // the kernel that carries the tail has just been launched: if that launch failed, some of its workgroups may never
+        // arrive -- leave the stream's ticket words zero for whoever launches next
+        if (hipPeekAtLastError() != hipSuccess) lidog_stats_tickets_reset(st);
+        return 0;
+    }
     return lidog_launch_sums_finish(tail.partial, nb, tail.C, tail.sums, tail.count, tail.fin, st);
 }
 

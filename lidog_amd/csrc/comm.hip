@@ -141,7 +141,7 @@ struct PeerComm {
     int32_t *err_dev;
     hipStream_t stream;   // the stream of the first call; every later call must use it (slot reuse relies on stream order)
     bool stream_set;
-    int skip_flag_at;     // fault injection (tests): the call with this sequence number raises no flags; 0 = never
+    uint64_t skip_flag_at;  // fault injection (tests): the call with this sequence number raises no flags; 0 = never
 };
 
 struct PeerArgs {
@@ -316,7 +316,7 @@ extern "C" int lidog_peer_allreduce_f64(void *comm, double *buf, int64_t n, void
     a.seq = ++c->seq;
     a.spin_limit = c->spin_limit;
     a.err = c->err_dev;
-    a.skip_flag = (c->skip_flag_at != 0 && (uint64_t)c->skip_flag_at == a.seq) ? 1 : 0;
+    a.skip_flag = (c->skip_flag_at != 0 && c->skip_flag_at == a.seq) ? 1 : 0;
     k_peer_allreduce<<<1, 256, 0, (hipStream_t)stream>>>(a, buf, (int)n);
     LIDOG_LAUNCH_CHECK();
     return 0;
@@ -336,7 +336,7 @@ extern "C" int lidog_peer_rebind_stream(void *comm, void *stream) {
 extern "C" int lidog_peer_inject_skip_flag(void *comm, int64_t seq) {
     PeerComm *c = (PeerComm *)comm;
     LIDOG_REQUIRE(c != nullptr && seq >= 0, "peer_inject_skip_flag: bad arguments");
-    c->skip_flag_at = (int)seq;
+    c->skip_flag_at = (uint64_t)seq;
     return 0;
 }
 

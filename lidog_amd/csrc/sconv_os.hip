@@ -22,8 +22,6 @@
 // both directions: `reverse` walks the bits from the top and takes the transposed weights of offset K-1-k.
 #include <stdlib.h>
 
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
 #include "sconv_mfma.h"
 #include "stats_tail.h"
@@ -78,31 +76,155 @@ __global__ __launch_bounds__(256) void k_os_wave_masks(const uint32_t *__restric
     if (i < n_pad && (threadIdx.x & 31) == 0) wave_masks[i >> 5] = m;
 }
 
+// ---- stable LSD radix sort of (key, row) pairs, hand-written for wave64: RS_BITS bits per pass.  A workgroup is ONE
+// wavefront that owns RS_CHUNK consecutive elements: (1) per-chunk digit histogram, (2) exclusive scan of the
+// digit-major [RS_BINS][chunks] table by one workgroup, (3) scatter -- the chunk is walked 64 elements at a time in
+// order; the lanes holding the same digit find each other with RS_BITS ballots, rank = popcount of the lower peers, the
+// lowest peer advances the digit's cursor: equal keys keep their input order (what the numpy restatement in
+// tests/test_gpu_sconv_os.py calls a stable argsort).  Replaces the CUB-compatibility wrapper the file used in round 4
+// (~10 launches of rocPRIM's merge-sort fallback per sort; here 3 per pass).
+#define RS_BITS 9
+#define RS_BINS (1 << RS_BITS)
+#define RS_CHUNK 2048
+
+__global__ __launch_bounds__(64) void k_rs_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int chunks,
+                                                int32_t *__restrict__ hist) {
+    __shared__ int32_t cnt[RS_BINS];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < RS_BINS; i += 64) cnt[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+    for (int64_t i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[(keys[i] >> shift) & (RS_BINS - 1)], 1);
+    __syncthreads();
+    for (int i = lane; i < RS_BINS; i += 64) hist[(int64_t)i * chunks + blockIdx.x] = cnt[i];
+}
+
+// in-place exclusive scan of m int32 by one workgroup of 1024 threads (m = RS_BINS * chunks: 89 k entries for the
+// stride-1 map of four bench scans)
+__global__ __launch_bounds__(1024) void k_rs_scan(int32_t *__restrict__ a, int64_t m) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 4096) {
+        // four consecutive entries per thread
+        const int64_t i0 = base + (int64_t)tid * 4;
+        int32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (i0 + j < m) ? a[i0 + j] : 0;
+        const int32_t mine = v[0] + v[1] + v[2] + v[3];
+        int32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int32_t before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        int32_t run = before + inc - mine;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < m) a[i0 + j] = run;
+            run += v[j];
+        }
+        __syncthreads();
+        if (tid == 1023) carry = before + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t *__restrict__ keys, const int32_t *__restrict__ vals,
+                                                   int64_t n, int shift, int chunks, const int32_t *__restrict__ hist,
+                                                   uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out) {
+    __shared__ int32_t cur[RS_BINS];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < RS_BINS; i += 64) cur[i] = hist[(int64_t)i * chunks + blockIdx.x];
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const bool live = i < hi;
+        const uint32_t key = live ? keys[i] : 0u;
+        const int32_t val = live ? vals[i] : 0;
+        const uint32_t d = (key >> shift) & (RS_BINS - 1);
+        uint64_t peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < RS_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & below);
+        const int32_t at = cur[d];
+        __syncthreads();   // every lane has read its cursor before the leaders move them (one wave: costs nothing)
+        if (live && rank == 0) cur[d] = at + __popcll(peers);
+        __syncthreads();
+        if (live) {
+            keys_out[at + rank] = key;
+            vals_out[at + rank] = val;
+        }
+    }
+}
+
 // launch order of the tiles: the ones with the most (wave, offset) blocks to multiply first, so that the grid ends on its
-// shortest workgroups (a tile walks 5 to 27 offsets).  key = 127 - blocks, sorted ascending (stable: ties by tile id).
-__global__ __launch_bounds__(256) void k_os_tile_keys(const uint32_t *__restrict__ wave_masks, int n_tiles,
-                                                      uint32_t *__restrict__ keys, int32_t *__restrict__ ids) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_tiles) return;
-    const int w = __popc(wave_masks[4 * t]) + __popc(wave_masks[4 * t + 1]) + __popc(wave_masks[4 * t + 2]) +
-                  __popc(wave_masks[4 * t + 3]);
-    keys[t] = (uint32_t)(127 - w);
-    ids[t] = t;
+// shortest workgroups (a tile walks 5 to 27 offsets).  key = 127 - blocks, ascending, ties by tile id: a counting sort by
+// ONE wavefront (a few thousand tiles; the same ballot ranking as k_rs_scatter).
+__global__ __launch_bounds__(64) void k_os_tile_order(const uint32_t *__restrict__ wave_masks, int n_tiles,
+                                                      int32_t *__restrict__ tile_order) {
+    __shared__ int32_t cur[128];
+    const int lane = threadIdx.x;
+    cur[lane] = 0;
+    cur[lane + 64] = 0;
+    __syncthreads();
+    auto key_of = [&](int t) {
+        const int w = __popc(wave_masks[4 * t]) + __popc(wave_masks[4 * t + 1]) + __popc(wave_masks[4 * t + 2]) +
+                      __popc(wave_masks[4 * t + 3]);
+        return 127 - w;     // w <= 4 * 27
+    };
+    for (int t = lane; t < n_tiles; t += 64) atomicAdd(&cur[key_of(t)], 1);
+    __syncthreads();
+    if (lane == 0) {
+        int run = 0;
+        for (int i = 0; i < 128; ++i) {
+            const int c = cur[i];
+            cur[i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int t0 = 0; t0 < n_tiles; t0 += 64) {
+        const int t = t0 + lane;
+        const bool live = t < n_tiles;
+        const int d = live ? key_of(t) : 0;
+        uint64_t peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const bool bit = (d >> b) & 1;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & below);
+        const int at = cur[d];
+        __syncthreads();
+        if (live && rank == 0) cur[d] = at + __popcll(peers);
+        __syncthreads();
+        if (live) tile_order[at + rank] = t;
+    }
 }
 
 static int64_t os_pad(int64_t n) { return (n + OS_TM - 1) / OS_TM * OS_TM; }
 
-static size_t os_sort_temp(int64_t n) {
-    size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                       (const int32_t *)nullptr, (int32_t *)nullptr, (int)n, 0, 32, (hipStream_t)0);
-    return bytes;
-}
+static int64_t rs_chunks(int64_t n) { return cdiv64(n, RS_CHUNK); }
 
 // bytes of workspace lidog_kernel_map_sorted needs for a map of n rows
 extern "C" int64_t lidog_kernel_map_sorted_ws(int64_t n) {
     if (n <= 0) return 256;
-    return (int64_t)os_sort_temp(n) + 4 * 4 * n + 8 * (os_pad(n) / OS_TM) + 4096;
+    return 256 + 4 * 4 * n + 4 * RS_BINS * rs_chunks(n) + 4096;
 }
 
 // perm [pad128(n)] int32: the rows in sorted order (-1 behind the last one); wave_masks [pad128(n) / 32] uint32: the OR
@@ -123,18 +245,26 @@ extern "C" int lidog_kernel_map_sorted(const int32_t *nbr, int64_t n, int32_t K,
     uint32_t *keys_out = (uint32_t *)p;           p += 4 * n;
     int32_t *rows = (int32_t *)p;                 p += 4 * n;
     uint32_t *masks = (uint32_t *)p;              p += 4 * n;
-    p = (char *)(((uintptr_t)p + 255) / 256 * 256);
-    size_t temp = os_sort_temp(n);
+    int32_t *hist = (int32_t *)p;
+    const int chunks = (int)rs_chunks(n);
+    const int passes = (K + RS_BITS - 1) / RS_BITS;
+    // the pairs ping-pong between (keys, a) and (keys_out, b); the row ids start where an odd / even number of passes
+    // leaves them in `perm`
+    int32_t *va = (passes & 1) ? rows : perm, *vb = (passes & 1) ? perm : rows;
     k_os_bitpos<<<1, 32, 0, st>>>(k_off, K, pos);
-    k_os_keys<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(nbr, n, K, pos, keys, rows, masks);
-    LIDOG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs((void *)p, temp, keys, keys_out, rows, perm, (int)n, 0, K, st));
+    k_os_keys<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(nbr, n, K, pos, keys, va, masks);
+    uint32_t *ka = keys, *kb = keys_out;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = pass * RS_BITS;
+        k_rs_hist<<<chunks, 64, 0, st>>>(ka, n, shift, chunks, hist);
+        k_rs_scan<<<1, 1024, 0, st>>>(hist, (int64_t)RS_BINS * chunks);
+        k_rs_scatter<<<chunks, 64, 0, st>>>(ka, va, n, shift, chunks, hist, kb, vb);
+        uint32_t *tk = ka; ka = kb; kb = tk;
+        int32_t *tv = va; va = vb; vb = tv;
+    }
     const int64_t n_pad = os_pad(n);
     k_os_wave_masks<<<(unsigned)cdiv64(n_pad, 256), 256, 0, st>>>(masks, perm, n, n_pad, wave_masks);
-    const int n_tiles = (int)(n_pad / OS_TM);
-    uint32_t *tkeys = keys, *tkeys_out = keys_out;      // the row keys are done with: reuse their arrays
-    int32_t *tids = rows;
-    k_os_tile_keys<<<(unsigned)cdiv64(n_tiles, 256), 256, 0, st>>>(wave_masks, n_tiles, tkeys, tids);
-    LIDOG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs((void *)p, temp, tkeys, tkeys_out, tids, tile_order, n_tiles, 0, 7, st));
+    k_os_tile_order<<<1, 64, 0, st>>>(wave_masks, (int)(n_pad / OS_TM), tile_order);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -564,11 +694,13 @@ static int os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t K, co
     LIDOG_REQUIRE(sums && ws, "sconv_os_stats: sums / workspace missing");
     LIDOG_REQUIRE(mean == nullptr || count > 0, "sconv_os_stats: finalising needs the row count");
     if (n == 0) return hipMemsetAsync(sums, 0, sizeof(double) * (2 * Cout + 1), st) == hipSuccess ? 0 : 1;
-    LIDOG_REQUIRE(os_pad(n) / OS_TM <= (int64_t)STATS_MAX_GROUPS * STATS_GROUP, "sconv_os_stats: too many tiles");
     OsStats stats = {};
     stats.mode = 1;
     BnFinish fin = {eps, momentum, mean, invstd, running_mean, running_var, nullptr, nullptr};
     if (lidog_stats_tail_make(&stats.tail, ws, sums, count, Cout, fin, st)) return 1;
+    // one partial row per tile: past what the two-level tail covers (4 096 tiles = 524 288 rows: six bench scans, or two
+    // of the 0.02 m stress scans) the rows are added by bn.hip:k_sums_finish in a launch of its own, which takes any count
+    if (os_pad(n) / OS_TM > (int64_t)STATS_MAX_GROUPS * STATS_GROUP) stats.tail.tickets = nullptr;
     int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, 0, bias, nullptr, Cin, Cout, out, stats, st, in_bn);
     if (rc) return rc;
     return lidog_stats_tail_finish(stats.tail, (int)(os_pad(n) / OS_TM), st);

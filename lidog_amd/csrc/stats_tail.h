@@ -147,6 +147,7 @@ __device__ __forceinline__ void lidog_stats_tail(const StatsTail &t, bool writer
 // ticket words of the launches queued on `stream` (zeroed when created; launches that share them must be ordered, which
 // launches on one stream are); NULL + error set on failure
 unsigned *lidog_stats_tickets(hipStream_t stream);
+int lidog_stats_tickets_reset(hipStream_t stream);   // zero them again (after a failed launch), in stream order
 
 // Fills `tail` for a launch on `st` and returns 0; with LIDOG_STATS_TAIL=0 (same-box A/B runs) tail.tickets stays NULL
 // and the caller launches bn.hip:k_sums_finish behind its kernel (lidog_stats_tail_finish does, when needed).

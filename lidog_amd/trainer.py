@@ -11,6 +11,8 @@ One process per GPU; gradients live in ONE contiguous fp32 buffer that is all-re
 a few large buckets launched as soon as their last gradient is produced (overlapping the rest of
 backward), then consumed by a single fused Adam kernel.
 """
+import os as _os
+
 import torch
 import torch.distributed as dist
 
@@ -18,10 +20,6 @@ from . import me as ME
 from .losses import DICELoss, SoftDICELoss
 from .optim import (FlatAdam, FlatParams, FlatSGD, GradientBuckets, make_optimizer, make_scheduler,  # noqa: F401
                     shard_indices)
-
-
-import os as _os
-_REUSE_MAPS = _os.environ.get("LIDOG_EXP_REUSE_MAPS", "0") == "1"
 
 
 class _CoordinatePrefetch:
@@ -38,16 +36,6 @@ class _CoordinatePrefetch:
 
     def _sparse_input(self, batch):
         coords = self._coords(batch)
-        if _REUSE_MAPS:   # timing experiment: the coordinate maps of a batch are built once and kept
-            cache = self.__dict__.setdefault("_kept", {})
-            if id(coords) in cache:
-                cm = cache[id(coords)][1]
-                st = ME.SparseTensor(features=batch["source_features0"], coordinate_manager=cm, coordinate_map_key=1)
-            else:
-                st = ME.SparseTensor(coordinates=coords, features=batch["source_features0"])
-                cache[id(coords)] = (coords, st.coordinate_manager)
-            self._last_manager = st.coordinate_manager
-            return st
         hit = self.__dict__.setdefault("_prepared", {}).pop(id(coords), None)
         if hit is not None and hit[0] is coords:
             st = ME.SparseTensor(features=batch["source_features0"], coordinates=coords, coordinate_manager=hit[1])
@@ -57,8 +45,6 @@ class _CoordinatePrefetch:
         return st
 
     def _after_step(self, prefetch, prefetch_ready):
-        if _REUSE_MAPS:
-            return
         self._trace = self._last_manager.trace
         if prefetch is not None and "coords_int" in prefetch:
             coords = prefetch["coords_int"]

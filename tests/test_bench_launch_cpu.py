@@ -76,3 +76,67 @@ def test_too_few_hardware_queues_are_reported_at_import():
     p = subprocess.run([sys.executable, "-W", "always", "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="8"),
                        capture_output=True, text=True, cwd=REPO)
     assert p.returncode == 0 and p.stdout.strip() == "8" and "8 hardware queues" in p.stderr, p.stderr[-500:]
+
+
+# ---------------------------------------------------------------- phase 2: the peer probe behind the headline line
+_RANK_OK = """
+    import json, os
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    dist.barrier()
+    if dist.get_rank() == 0:
+        print(json.dumps({"n_gpus": dist.get_world_size()}), flush=True)
+    dist.destroy_process_group()
+    """
+
+
+def _probe_script(tmp_path, body):
+    probe = tmp_path / "probe.py"
+    probe.write_text(textwrap.dedent(body))
+    return str(probe)
+
+
+def test_probe_phase_runs_after_the_line_and_its_exit_code_is_ignored(tmp_path):
+    """after rank 0's line a SECOND group of fresh processes runs the probe script under the same launcher line; what it
+    prints goes to stderr, a failing probe does not change the exit code"""
+    probe = _probe_script(tmp_path, """
+        import os, sys
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        assert "LIDOG_PEER_ALLREDUCE" not in os.environ
+        dist.barrier()
+        if dist.get_rank() == 0:
+            sys.stderr.write('{"peer_probe": {"ranks": %d}}\\n' % dist.get_world_size())
+        dist.destroy_process_group()
+        sys.exit(7)
+        """)
+    p, _ = _run(tmp_path, _RANK_OK, extra_env={"LIDOG_BENCH_PROBE_SCRIPT": probe, "LIDOG_PEER_ALLREDUCE": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")] == [{"n_gpus": 2}]
+    assert '{"peer_probe": {"ranks": 2}}' in p.stderr and "its exit code is ignored" in p.stderr
+    assert "peer_probe" not in p.stdout
+
+
+def test_probe_phase_is_killed_by_its_own_watchdog(tmp_path):
+    probe = _probe_script(tmp_path, """
+        import time
+        time.sleep(600)
+        """)
+    p, dt = _run(tmp_path, _RANK_OK, extra_env={"LIDOG_BENCH_PROBE_SCRIPT": probe, "LIDOG_BENCH_PROBE_WATCHDOG_S": "4"})
+    assert p.returncode == 0 and dt < 120, (p.returncode, dt)
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1
+    assert "peer probe killed" in p.stderr
+
+
+def test_no_probe_after_a_failed_run_or_when_switched_off(tmp_path):
+    probe = _probe_script(tmp_path, """
+        import sys
+        sys.stderr.write("PROBE RAN\\n")
+        """)
+    p, _ = _run(tmp_path, """
+        import sys
+        sys.exit(3)
+        """, extra_env={"LIDOG_BENCH_PROBE_SCRIPT": probe})
+    assert p.returncode != 0 and "PROBE RAN" not in p.stderr
+    p, _ = _run(tmp_path, _RANK_OK, extra_env={"LIDOG_BENCH_PROBE_SCRIPT": probe, "LIDOG_BENCH_PROBE": "0"})
+    assert p.returncode == 0 and "PROBE RAN" not in p.stderr

@@ -312,3 +312,36 @@ def test_two_rank_bench_keeps_replicas_identical():
     assert line["replicas_identical"] == {"parameters": True, "syncbn_running_statistics": True}
     assert line["rccl_ranks_seen"]["torch_process_group"] == 2 and line["config"]["peer_note"] == "on"
     assert "peer_one_shot" in line["statistics_allreduce_us"] and "peer_error" not in line
+    # phase 2 (bench.launch_ranks -> probe_phase): AFTER the line, a second group of fresh processes measured one
+    # statistics message through the peer one-shot path (probe mode) and torch.distributed; stderr carries its JSON line
+    probe = [l for l in out.stderr.splitlines() if l.startswith('{"peer_probe"')]
+    assert probe, out.stderr[-3000:]
+    pr = json.loads(probe[-1])["peer_probe"]
+    assert pr["ranks"] == 2 and pr["one_gpu"] and pr["peer_sum_ok"] is True and pr["peer_error"] is None
+    assert pr["us"]["peer_one_shot"] > 0 and pr["us"]["torch_distributed"] > 0
+    assert "its exit code is ignored" in out.stderr
+
+
+def test_ranks_started_by_a_foreign_launcher_run_the_probe_themselves():
+    """the driver starts the ranks with its own `python -m torch.distributed.run ... bench.py --gpus N` line: no parent of
+    this repository exists, so every rank starts its probe child after it has printed, torn down and left the group"""
+    import json
+    import socket
+    import subprocess
+    env = dict(os.environ, LIDOG_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LIDOG_PEER_ALLREDUCE"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--min-seconds", "0.1", "--batch", "1", "--config", "source8k"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["statistics_allreduce"] != "peer one-shot"   # the step itself: default path
+    probe = [l for l in out.stderr.splitlines() if '{"peer_probe"' in l]
+    assert probe, out.stderr[-3000:]
+    pr = json.loads(probe[-1][probe[-1].index('{"peer_probe"'):])["peer_probe"]
+    assert pr["ranks"] == 2 and pr["peer_sum_ok"] is True and pr["us"]["peer_one_shot"] > 0

@@ -187,19 +187,79 @@ def test_conv_layer_at_one_bench_scan_is_bit_exact(core):
         L.lidog_set_sparse_core(1)
 
 
-def test_whole_network_on_one_bench_scan_against_the_oracle():
+def test_conv_layer_on_the_bench_batch_takes_the_output_stationary_kernel_and_is_bit_exact():
+    """What the bench runs at bs 4: block8's 96 -> 96 3^3 convolution on the stride-1 map of FOUR scans (355 k voxels,
+    2 700+ tiles of 128 rows, 4.5 pairs per row) goes through csrc/sconv_os.hip (rows sorted by neighbour mask, no product
+    rows) -- forward and data gradient bit-exact against the oracle's fmaf chains, weight gradient within 2e-5 of its
+    scale.  (tests/test_gpu_sconv_os.py pins the kernel to the two-pass path on a bs-2 map; this is the oracle itself
+    on the map the headline workload builds.)"""
+    import oracle.me_cpu as OME
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    OME.set_mode("exact")
+    coords = synth.make_batch((2, 3, 4, 5), "kitti120k", "cpu")["coords_int"]
+    n = coords.shape[0]
+    ocm, gcm = _oracle_and_gpu(coords)
+    m = gcm.kernel_map(1, 1, 3)
+    assert n >= 128 * ME._SCONV_OS_MIN_TILES and m.sorted() is not None        # the default rule hands it to the kernel
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(n, 96, generator=g)
+    gy = torch.randn(n, 96, generator=g)
+    co = OME.MinkowskiConvolution(96, 96, kernel_size=3, stride=1, bias=False, dimension=3)
+    cg = ME.MinkowskiConvolution(96, 96, kernel_size=3, stride=1, bias=False, dimension=3).cuda()
+    cg.load_state_dict(co.state_dict())
+    xo = x.clone().requires_grad_(True)
+    xg = x.clone().cuda().requires_grad_(True)
+    yo = co(OME.SparseTensor(xo, coordinate_manager=ocm, coordinate_map_key=1))
+    yg = cg(ME.SparseTensor(xg, coordinate_manager=gcm, coordinate_map_key=1))
+    assert torch.equal(yo.F.detach(), yg.F.detach().cpu()), (yo.F.detach() - yg.F.detach().cpu()).abs().max()
+    yo.F.backward(gy)
+    yg.F.backward(gy.cuda())
+    assert torch.equal(xo.grad, xg.grad.cpu()), (xo.grad - xg.grad.cpu()).abs().max()
+    scale = co.kernel.grad.abs().max().item()
+    assert (co.kernel.grad - cg.kernel.grad.cpu()).abs().max().item() <= 2e-5 * scale
+
+
+_WHOLE_NET = {}
+
+
+def _whole_network_oracle(kw, sd, coords, labels, bev_labels):
+    """the reference wiring on the CPU oracle (blas mode), once per test session: logits, BEV logits, loss, gradients"""
+    if "ref" not in _WHOLE_NET:
+        import oracle.me_cpu as OME
+        from lidog_amd.minkunet import make_models
+        from oracle.ref_torch import Encoder2DRef, dice_loss_ref, soft_dice_loss_ref, sparse2super_ref
+        OME.set_mode("blas")
+        try:
+            ref_cls = make_models(OME, Encoder2DRef, lambda x, bound, voxel, pool: sparse2super_ref(x.C, x.F, bound, voxel, pool))
+            ref = ref_cls.MinkUNet34BEV(**kw)
+            ref.load_state_dict(sd)
+            ref.train()
+            rs, rb = ref(OME.SparseTensor(coordinates=coords, features=torch.ones(coords.shape[0], 1)), is_train=True)
+            rl = 0.5 * soft_dice_loss_ref(rs.F, labels) + 0.5 * dice_loss_ref(rb["block8"].view(-1, 7), bev_labels.view(-1))
+            rl.backward()
+        finally:
+            OME.set_mode("exact")
+        _WHOLE_NET["ref"] = (rs.F.detach(), rb["block8"].detach(), rl.detach(),
+                             [(n, q.grad.double().flatten()) for n, q in ref.named_parameters()])
+    return _WHOLE_NET["ref"]
+
+
+@pytest.mark.parametrize("os_mode", [1, 2], ids=["default_rule", "bench_path_os_kernel_everywhere"])
+def test_whole_network_on_one_bench_scan_against_the_oracle(os_mode, monkeypatch):
     """MinkUNet34BEV (B = 50 m, training-mode BatchNorm) on scan 0 of the bench workload -- 88 117 voxels, the per-stride
     counts of BASELINE.md -- against the same wiring on the CPU oracle (ME's CPU algorithm, blas mode): per-point logits
     and BEV logits within 1e-4 (north_star), loss within 1e-5, voxel counts per stride equal, and the gradient of every
-    parameter (the whole backward chain at bench size)"""
+    parameter (the whole backward chain at bench size).  One scan is 689 tiles, below the 1 500 the default rule asks for:
+    the second variant forces what the bs-4 bench runs -- trunk executor + every fusion + the output-stationary kernel
+    (csrc/sconv_os.hip) on every symmetric 3^3 map -- in front of the oracle directly, same bars."""
     import lidog_amd
     import lidog_amd.me as ME
-    import oracle.me_cpu as OME
     from helpers import seeded_state_dict
-    from lidog_amd import synth
+    from lidog_amd import _lib, synth
     from lidog_amd.losses import DICELoss, SoftDICELoss
-    from lidog_amd.minkunet import make_models
-    from oracle.ref_torch import Encoder2DRef, dice_loss_ref, soft_dice_loss_ref, sparse2super_ref
+    monkeypatch.setattr(ME, "_SCONV_OS", os_mode)
+    monkeypatch.setattr(ME, "_OS_HINT", {})
     b = synth.make_batch((0,), "kitti120k", "cpu")
     coords, labels, bev_labels = b["coords_int"], b["source_sem_labels0"], b["source_bev_labels0"]["block8"]
     kw = dict(in_channels=1, out_channels=7, D=3, initial_kernel_size=5, decoder_2d_level=["block8"], mapping_bound_2d=50.0)
@@ -213,26 +273,22 @@ def test_whole_network_on_one_bench_scan_against_the_oracle():
         0.5 * DICELoss(ignore_label=-1)(bev["block8"].view(-1, 7), bev_labels.cuda().view(-1))
     cm = st.coordinate_manager
     assert tuple(cm.maps[s].n for s in (1, 2, 4, 8, 16)) == synth.BASELINE_COUNTS["kitti120k"]
-    OME.set_mode("blas")
-    try:
-        ref_cls = make_models(OME, Encoder2DRef, lambda x, bound, voxel, pool: sparse2super_ref(x.C, x.F, bound, voxel, pool))
-        ref = ref_cls.MinkUNet34BEV(**kw)
-        ref.load_state_dict(sd)
-        ref.train()
-        rs, rb = ref(OME.SparseTensor(coordinates=coords, features=torch.ones(coords.shape[0], 1)), is_train=True)
-        rl = 0.5 * soft_dice_loss_ref(rs.F, labels) + 0.5 * dice_loss_ref(rb["block8"].view(-1, 7), bev_labels.view(-1))
-        rl.backward()
-    finally:
-        OME.set_mode("exact")
+    if os_mode == 2:
+        # the bench's path: executor (all fusions on), and every 3^3 map of a coordinate map onto itself has sorted rows
+        assert type(sem.F.grad_fn).__name__ == "_TrunkFnBackward"
+        assert _lib.load().lidog_trunk_fusions(-1) == 7
+        assert all(cm.kmaps[(s, s, 3, 1)].sorted() is not None for s in (1, 2, 4, 8, 16))
+    else:
+        assert cm.kmaps[(1, 1, 3, 1)].sorted() is None
+    rs_F, rb8, rl, rgrads = _whole_network_oracle(kw, sd, coords, labels, bev_labels)
     loss.backward()
     torch.cuda.synchronize()
-    rs_F, rl = rs.F.detach(), rl.detach()
     rs = type("T", (), {"F": rs_F})
-    rb = {"block8": rb["block8"].detach()}
+    rb = {"block8": rb8}
     # the whole backward chain at bench size: every parameter's gradient against the oracle's
     worst, rels = ("", 0.0), []
-    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        a, c = p.grad.detach().cpu().double().flatten(), q.grad.double().flatten()
+    for (n, p), (_, c) in zip(model.named_parameters(), rgrads):
+        a = p.grad.detach().cpu().double().flatten()
         e = float((a - c).norm() / c.norm())
         rels.append(e)
         if e > worst[1]:

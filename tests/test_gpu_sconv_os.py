@@ -172,3 +172,44 @@ def test_evaluation_mode_batchnorm_epilogue_equals_the_two_pass_form():
         call("lidog_sconv_os_bn", ptr(x), ptr(m.nbr), n, 27, ptr(perm), ptr(wm), ptr(order), ptr(W), None, Cin, Cout,
              ptr(mean), ptr(invstd), ptr(w), ptr(b), ptr(residual), relu, ptr(o2))
         assert torch.equal(o1, o2)
+
+
+def test_statistics_form_past_4096_tiles_takes_the_separate_finish():
+    """one partial row per 128-row tile, and the in-kernel tail covers 128 x 32 of them; six bench scans
+    (533 k rows = 4 167 tiles; `bench.py --batch 6`, or two 0.02 m stress scans) used to raise "too many tiles" inside the
+    training step.  Past that size the rows are added by k_sums_finish in a launch of its own: same convolution bits as
+    the two-pass path, sums equal to the float64 column sums of the output, run-to-run identical."""
+    from lidog_amd import _lib, synth
+    from lidog_amd._lib import call, ptr
+    L = _lib.load()
+    b = synth.make_batch(range(6), "kitti120k", "cuda")
+    ME, cm = _setup(b["coords_int"].cpu())
+    m = cm.kernel_map(1, 1, 3)
+    n, Cin, Cout = m.n_out, 32, 32
+    assert (n + 127) // 128 > 4096
+    perm, wm, order = _sorted(m)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, Cin, generator=g).cuda()
+    W = (torch.randn(27, Cin, Cout, generator=g) * 0.1).cuda()
+    T = torch.empty(m.P, Cout, device="cuda")
+    o1, o2 = torch.empty(n, Cout, device="cuda"), torch.empty(n, Cout, device="cuda")
+    rp, rl = m.rows("out")
+    ME._gemm(x, m.pair_in, W, None, m, Cin, Cout, T, None)
+    call("lidog_sconv_reduce_rows", ptr(T), ptr(rp), ptr(rl), n, Cout, None, None, ptr(o1))
+    su = torch.empty(2 * Cout + 1, dtype=torch.float64, device="cuda")
+    ws = torch.empty(L.lidog_sconv_os_stats_ws(n, Cout), dtype=torch.float64, device="cuda")
+    me, inv = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    keep = None
+    for rep in range(2):
+        su.zero_()
+        call("lidog_sconv_os_stats", ptr(x), ptr(m.nbr), n, 27, ptr(perm), ptr(wm), ptr(order), ptr(W), None, Cin, Cout,
+             ptr(o2), ptr(su), ptr(ws), float(n), 1e-5, 0.1, ptr(me), ptr(inv), None, None)
+        assert torch.equal(o1, o2)
+        ref = torch.cat([o2.double().sum(0), (o2.double() ** 2).sum(0)])
+        assert ((su[:-1] - ref).abs() <= 1e-10 * ref.abs() + 1e-9).all() and su[-1].item() == n
+        assert torch.allclose(me, o2.double().mean(0).float(), rtol=1e-5, atol=1e-6)
+        if keep is not None:
+            assert torch.equal(su, keep)
+        keep = su.clone()
+    # the small launch right behind it still finds its stream's ticket words zeroed (the in-kernel tail)
+    test_statistics_form_and_bench_size_map()
