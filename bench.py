@@ -798,7 +798,10 @@ def main():
     if probe_port is not None:
         # the headline line is out (printed and flushed above) and this rank holds no communicator any more; the child is a
         # fresh process on this rank's GPU, bounded by its own watchdog, exit code ignored
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1",
+        # (without the launcher's TORCHELASTIC_* variables: with TORCHELASTIC_USE_AGENT_STORE set, rank 0 would look for the
+        # launcher agent's store on the new port instead of serving one)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(probe_port))
         probe_phase([sys.executable], env)
 

@@ -78,6 +78,11 @@ int lidog_kernel_map_bits(const int32_t *coords_out, int64_t n_out, const uint64
                           int64_t in_cap, const int32_t *offsets_host, int32_t K, const uint32_t *bits, int32_t x0,
                           int32_t y0, int32_t z0, int32_t nx, int32_t ny, int32_t nz, int32_t stride, int32_t nb,
                           int32_t *nbr, void *stream);
+/* Neighbour table of a kernel map whose offsets are a SUBSET of another map's over the same coordinate map (same tensor
+ * stride and dilation): the 3^3 map of the stride-1 BasicBlocks (minkunet_bev.py:371, block8) from the stem's 5^3 table
+ * (:57, conv0p1s1).  nbr [K, n] row k = nbr_big [K_big, n] row sel_host[k]; no hash probes, same table bit for bit. */
+int lidog_kernel_map_subset(const int32_t *nbr_big, int64_t n, int32_t K_big, const int32_t *sel_host, int32_t K,
+                            int32_t *nbr, void *stream);
 
 /* Kernel map, neighbour-table form, k-major: nbr[k * n_out + o] = row of the input map holding
  * coordinate out[o] + offsets[k], or -1.  offsets_host is a HOST array [K,3] (x,y,z), K <= 125. */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lidog_bn_bwd_reduce_blocks": [_i64, _i32],
     "lidog_stats_max_blocks": [],
     "lidog_sconv_cin1": [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p],
+    "lidog_kernel_map_subset": [_p, _i64, _i32, _p, _i32, _p, _p],
     "lidog_kernel_map_sorted_ws": [_i64],
     "lidog_kernel_map_sorted": [_p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p],
     "lidog_sconv_os": [_p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _p, _i32, _i32, _p, _p],
@@ -136,7 +137,7 @@ _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "
 
 # lidog_abi_version() of the library these signatures were written against: a stale .so (or a header an external caller
 # compiled against long ago) would take mis-sized arguments without any diagnostic
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

@@ -17,7 +17,7 @@ void lidog_set_error(const char *fmt, ...) {
 extern "C" const char *lidog_last_error(void) { return g_err; }
 // bumped whenever an entry point changes its arguments or their meaning (lidog_amd/_lib.py checks it at load time);
 // 4 = round 4: in-kernel statistics finish (workspace sizes), peer all-reduce stream binding / fault hooks
-extern "C" int lidog_abi_version(void) { return 5; }
+extern "C" int lidog_abi_version(void) { return 6; }
 
 extern "C" int64_t lidog_hash_capacity(int64_t n) {
     int64_t cap = 1024;
@@ -511,6 +511,53 @@ extern "C" int lidog_kernel_map(const int32_t *coords_out, int64_t n_out, const 
     dim3 grid((unsigned)cdiv64(n_out, 256), (unsigned)K);
     k_kernel_map<<<grid, 256, 0, st>>>((const int4 *)coords_out, n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), offs,
                                        nbr);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ a kernel map as a subset of a larger one's offsets
+// The 3^3 offsets of a coordinate map onto itself are 27 of the 125 offsets of its 5^3 map (same tensor stride, same
+// dilation): the stem's neighbour table (conv0p1s1, utils/models/minkunet_bev.py:57) already holds every neighbour the
+// stride-1 3^3 convolutions of block8 (:371) will ask for.  Row k of the small table = row sel[k] of the large one: one
+// streaming copy instead of 27 n bitmap tests + hash probes, and the same table bit for bit by construction.
+struct KSubset {
+    int32_t sel[27];
+};
+
+__global__ __launch_bounds__(256) void k_nbr_subset(const int4 *__restrict__ big, int64_t n, KSubset sel,
+                                                    int4 *__restrict__ nbr) {
+    // one int4 (four rows) per thread; rows of the [K, n] tables are 16-byte aligned when n % 4 == 0
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (q * 4 >= n) return;
+    nbr[(int64_t)k * (n / 4) + q] = big[(int64_t)sel.sel[k] * (n / 4) + q];
+}
+
+__global__ __launch_bounds__(256) void k_nbr_subset1(const int32_t *__restrict__ big, int64_t n, KSubset sel,
+                                                     int32_t *__restrict__ nbr) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (r >= n) return;
+    nbr[(int64_t)k * n + r] = big[(int64_t)sel.sel[k] * n + r];
+}
+
+extern "C" int lidog_kernel_map_subset(const int32_t *nbr_big, int64_t n, int32_t K_big, const int32_t *sel_host,
+                                       int32_t K, int32_t *nbr, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    LIDOG_REQUIRE(K >= 1 && K <= 27 && K_big >= K && K_big <= 125, "kernel_map_subset: K=%d of K_big=%d", K, K_big);
+    if (n == 0) return 0;
+    LIDOG_REQUIRE(nbr_big && sel_host && nbr, "kernel_map_subset: null argument");
+    KSubset sel;
+    for (int k = 0; k < K; ++k) {
+        LIDOG_REQUIRE(sel_host[k] >= 0 && sel_host[k] < K_big, "kernel_map_subset: offset %d selects row %d of %d", k,
+                      sel_host[k], K_big);
+        sel.sel[k] = sel_host[k];
+    }
+    if (n % 4 == 0 && ((uintptr_t)nbr_big % 16) == 0 && ((uintptr_t)nbr % 16) == 0)
+        k_nbr_subset<<<dim3((unsigned)cdiv64(n / 4, 256), (unsigned)K), 256, 0, st>>>((const int4 *)nbr_big, n, sel,
+                                                                                     (int4 *)nbr);
+    else
+        k_nbr_subset1<<<dim3((unsigned)cdiv64(n, 256), (unsigned)K), 256, 0, st>>>(nbr_big, n, sel, nbr);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }

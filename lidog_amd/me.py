@@ -316,6 +316,7 @@ class CoordinateManager:
         self.uniq = None
         self._ready = None      # event on the side stream once prepare() has finished
         self._owned = [self.err]  # device tensors created here (handed to the consumer stream by handover())
+        self._nbr_tables = {}     # kernel-map key -> neighbour table, from the moment its kernel has been queued
 
     def _own(self, *tensors):
         self._owned.extend(tensors)
@@ -527,8 +528,13 @@ class CoordinateManager:
         K = offs.shape[0]
         n_in, n_out = cin.n, cout.n
         nbr = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
-        bits, box = self._bitmap(s_in)
-        if bits is not None:
+        # a 3^3 map of a coordinate map onto itself whose 5^3 map exists already (the stem's, built first: the trace is in
+        # forward order): its 27 offsets are rows of that table -- no probes at all (lidog_kernel_map_subset)
+        big = self._nbr_tables.get((s_in, s_out, 5, dilation)) if (_SUBSET_MAPS and kernel_size == 3 and s_in == s_out) else None
+        bits, box = (None, None) if big is not None else self._bitmap(s_in)
+        if big is not None:
+            call("lidog_kernel_map_subset", ptr(big), n_out, 125, _SUBSET_3_OF_5.ctypes.data, K, ptr(nbr))
+        elif bits is not None:
             call("lidog_kernel_map_bits", ptr(cout.coords), n_out, ptr(cin.keys), ptr(cin.vals), cin.cap,
                  offs.ctypes.data, K, ptr(bits), *box, ptr(nbr))
         else:
@@ -550,6 +556,7 @@ class CoordinateManager:
         call("lidog_kernel_map_pairs", ptr(nbr), n_out, n_in, K, ptr(k_off), ptr(pair_in), ptr(pair_out),
              ptr(pos_out), ptr(pos_in), ptr(ws))
         self._own(*[t for t in (nbr, k_off, pair_in, pair_out, pos_out, pos_in) if t is not None])
+        self._nbr_tables[key] = nbr
         return (K, n_in, n_out, k_off, pair_in, pair_out, pos_out, pos_in, nbr)
 
     def _kernel_map_finish(self, pd, k_off_host, tiles, key=None):
@@ -733,6 +740,10 @@ def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles=None):
          n_tiles, Cin, Cout, ptr(out), ptr(scatter))
 
 
+# row of the 5^3 neighbour table that holds offset k of the 3^3 kernel (both x fastest, centred)
+_SUBSET_3_OF_5 = np.array([(dz + 2) * 25 + (dy + 2) * 5 + (dx + 2) for dz in (-1, 0, 1) for dy in (-1, 0, 1)
+                           for dx in (-1, 0, 1)], dtype=np.int32)
+_SUBSET_MAPS = os.environ.get("LIDOG_MAP_SUBSET", "1") != "0"     # A/B switch: 0 = probe the 3^3 map as every other one
 # occupancy bitmaps in front of the kernel maps' hash probes (CoordinateManager._bitmap); 0 = plain probes
 _BITMAPS = os.environ.get("LIDOG_MAP_BITMAPS", "1") != "0"
 _BITMAP_MAX_BYTES = int(os.environ.get("LIDOG_MAP_BITMAP_MAX_MB", "1024")) << 20

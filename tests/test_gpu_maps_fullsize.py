@@ -87,6 +87,28 @@ def test_prepared_maps_at_bench_size_equal_the_oracle():
     assert gcm.maps[1].bits is not None
 
 
+def test_3x3x3_map_selected_from_the_stem_table_equals_the_probed_one(monkeypatch):
+    """the stride-1 3^3 map is 27 rows of the stem's 5^3 neighbour table (lidog_kernel_map_subset): same neighbour table,
+    pair lists and offsets as the map probed on its own and as the oracle's, at bench size (odd and 4-aligned row counts)"""
+    import lidog_amd.me as ME
+    from lidog_amd import synth
+    for seeds, aligned in (((0, 1), True), ((3,), False)):
+        coords = synth.make_batch(seeds, "kitti120k", "cpu")["coords_int"]
+        n = coords.shape[0]
+        coords = coords[:n - n % 4 if aligned else (n if n % 4 else n - 1)].contiguous()   # int4 and scalar copy kernels
+        ocm, gcm = _oracle_and_gpu(coords)
+        k5 = gcm.kernel_map(1, 1, 5)
+        assert (1, 1, 5, 1) in gcm._nbr_tables
+        km = _assert_same_map(ocm, gcm, (1, 1, 3))                # built as a subset: the 5^3 table exists
+        monkeypatch.setattr(ME, "_SUBSET_MAPS", False)
+        probed = ME.SparseTensor(coordinates=coords.cuda(), features=torch.ones(coords.shape[0], 1, device="cuda")).coordinate_manager
+        probed.kernel_map(1, 1, 5)
+        kp = probed.kernel_map(1, 1, 3)
+        monkeypatch.setattr(ME, "_SUBSET_MAPS", True)
+        assert torch.equal(kp.nbr, km.nbr) and torch.equal(kp.pair_in, km.pair_in) and torch.equal(kp.pair_out, km.pair_out)
+        assert torch.equal(km.nbr, k5.nbr[torch.from_numpy(ME._SUBSET_3_OF_5).long().cuda()])
+
+
 @pytest.mark.parametrize("shift", [(-3, 5, -7), (1001, -999, 13)])
 def test_bitmap_maps_with_negative_and_unaligned_boxes(shift, monkeypatch):
     """a box whose low corner is not a multiple of the coarser strides, all-negative and mixed-sign coordinates"""

@@ -339,3 +339,46 @@ def test_bottleneck_block_matches_the_oracle():
     for (k, po), (_, pg) in zip(blk_o.named_parameters(), blk_g.named_parameters()):
         a, b = pg.grad.cpu().double().flatten(), po.grad.double().flatten()
         assert float((a - b).norm() / (b.norm() + 1e-30)) <= 1e-4, k
+
+
+_TAIL_CODE = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from lidog_amd import _lib
+from lidog_amd._lib import call, ptr
+L = _lib.load()
+out = []
+for n, C in ((400000, 96), (1000003, 32), (70001, 256)):
+    g = torch.Generator().manual_seed(n + C)
+    x = (torch.randn(n, C, generator=g) * 3 + 1).cuda()
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device="cuda")
+    ws = torch.empty(L.lidog_bn_reduce_ws(C, 1), dtype=torch.float64, device="cuda")
+    mean, invstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    for rep in range(3):
+        call("lidog_bn_stats", ptr(x), n, C, 1, ptr(sums), ptr(ws), float(n), 1e-5, 0.1, ptr(mean), ptr(invstd), None, None)
+    out.append(torch.cat([sums, mean.double(), invstd.double()]).cpu())
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_in_kernel_statistics_tail_equals_the_separate_finish_kernel(tmp_path):
+    """the last-arriver tail of the statistics reductions (csrc/stats_tail.h: write-through stores, one ticket
+    add per workgroup) against bn.hip:k_sums_finish in a launch of its own (LIDOG_STATS_TAIL=0, read once per process:
+    two child processes) on grids that span every XCD -- sums, mean and invstd to 1e-12, three launches in a row on
+    one stream (the ticket words must come back to zero)."""
+    import os
+    import subprocess
+    import sys
+    from helpers import REPO
+    res = {}
+    for tail in ("1", "0"):
+        f = str(tmp_path / f"tail{tail}.pt")
+        env = dict(os.environ, LIDOG_STATS_TAIL=tail)
+        p = subprocess.run([sys.executable, "-c", _TAIL_CODE % REPO, f], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tail] = torch.load(f)
+    # the two finishes add the same per-workgroup partial rows in different groupings (32-row groups vs 64 strided
+    # chains), so the float64 sums agree to rounding, not bit for bit; a partial row read STALE by the last arriver (the
+    # failure the hand-off protocol must exclude) would be off by ~1/workgroups, eleven orders of magnitude more
+    for a, b in zip(res["1"], res["0"]):
+        assert ((a - b).abs() <= 1e-12 * b.abs() + 1e-12).all(), (a - b).abs().max()
