@@ -261,6 +261,9 @@ int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
                            int Cin, int Cout, float *T, const int32_t *scatter, InBn in_bn, hipStream_t st) {
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
+    // (Round 5: 256-column workgroups for the 256-channel layers -- eight MFMA column tiles per wave, the 128 gathered rows
+    // of a tile staged once instead of by two workgroups; 248 registers, two workgroups per CU, bit-identical -- measured in
+    // the step, same box, alternating: 47.92 / 47.96 -> 48.21 / 48.15 ms.  Not kept.)
     dim3 grid((unsigned)n_tiles, (unsigned)(Cout / (32 * nt)));
 #define LAUNCHF(NT_, MW_, F_)                                                                                     \
     k_sconv_gemm_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, \
