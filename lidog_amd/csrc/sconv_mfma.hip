@@ -484,6 +484,16 @@ __global__ __launch_bounds__(64 * NW, (FOLD && MT * NT == 16) ? 3 : 1) void k_sc
     }
 }
 
+// Round 5, built and measured for the 96 x 96 case, not kept:
+//  * four waves of v_mfma_f32_16x16x4_f32 (each a 48 x 48 quadrant = 3 x 3 tiles, LDS rows padded to 112 floats; 90-98
+//    registers, four waves per SIMD instead of 164-174 / two): 0.368 / 0.262 ms alone on the stride-1 / stride-2 layers
+//    against 0.380 / 0.292 for the three-wave 32x32x2 form below, and 48.91 / 48.92 against 48.72 / 48.78 ms IN the step
+//    (same box, alternating): the kernel moves 1 158 MB of gathered rows in 0.37 ms either way (3.1 TB/s out of L2 /
+//    Infinity Cache), and a faster lane kernel only takes that bandwidth from the launch stream sooner;
+//  * the centre offset of a 3^3 map taken as identity pairs (row = pair number, no index loads, both operands streamed):
+//    0.367 vs 0.368 ms alone, 48.95 / 48.91 vs 48.91 / 48.92 in the step -- the two-level software pipeline already hides
+//    the index loads, and consecutive rows are no cheaper to fetch than gathered ones (locality is not the limiter).
+// profiles/r05_ab_wgrad96.txt
 static int tile32(int C) { return (C % 128 == 0) ? 4 : (C % 96 == 0) ? 3 : (C % 64 == 0) ? 2 : 1; }
 
 // (NW, NGRP) per tile count: every wave gets the same number of MFMA tiles, or rows are split over groups
