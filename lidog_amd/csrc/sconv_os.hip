@@ -77,62 +77,63 @@ __global__ __launch_bounds__(256) void k_os_wave_masks(const uint32_t *__restric
 }
 
 // ---- stable LSD radix sort of (key, row) pairs, hand-written for wave64: RS_BITS bits per pass.  A workgroup is ONE
-// wavefront that owns RS_CHUNK consecutive elements: (1) per-chunk digit histogram, (2) exclusive scan of the
-// digit-major [RS_BINS][chunks] table by one workgroup, (3) scatter -- the chunk is walked 64 elements at a time in
+// wavefront that owns RS_CHUNK consecutive elements: (1) per-chunk digit histogram (+ per-digit totals), (2) exclusive scan
+// of the digit-major [RS_BINS][chunks] table, one wavefront per digit, (3) scatter -- the chunk is walked 64 elements at a time in
 // order; the lanes holding the same digit find each other with RS_BITS ballots, rank = popcount of the lower peers, the
 // lowest peer advances the digit's cursor: equal keys keep their input order (what the numpy restatement in
 // tests/test_gpu_sconv_os.py calls a stable argsort).  Replaces the CUB-compatibility wrapper the file used in round 4
 // (~10 launches of rocPRIM's merge-sort fallback per sort; here 3 per pass).
 #define RS_BITS 9
 #define RS_BINS (1 << RS_BITS)
-#define RS_CHUNK 2048
+#define RS_CHUNK 1024
+#define OS_TILE_ORDER_LDS 16384
 
+// hist [RS_BINS][chunks] (digit-major) + totals [RS_BINS] (zeroed by the caller; integer atomics: order-independent)
 __global__ __launch_bounds__(64) void k_rs_hist(const uint32_t *__restrict__ keys, int64_t n, int shift, int chunks,
-                                                int32_t *__restrict__ hist) {
+                                                int32_t *__restrict__ hist, int32_t *__restrict__ totals) {
     __shared__ int32_t cnt[RS_BINS];
     const int lane = threadIdx.x;
     for (int i = lane; i < RS_BINS; i += 64) cnt[i] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
-    for (int64_t i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[(keys[i] >> shift) & (RS_BINS - 1)], 1);
+    uint32_t kreg[RS_CHUNK / 64];      // every load of the chunk in flight before the first use
+#pragma unroll
+    for (int r = 0; r < RS_CHUNK / 64; ++r) {
+        const int64_t i = lo + 64 * r + lane;
+        kreg[r] = keys[i < hi ? i : hi - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_CHUNK / 64; ++r)
+        if (lo + 64 * r + lane < hi) atomicAdd(&cnt[(kreg[r] >> shift) & (RS_BINS - 1)], 1);
     __syncthreads();
-    for (int i = lane; i < RS_BINS; i += 64) hist[(int64_t)i * chunks + blockIdx.x] = cnt[i];
+    for (int i = lane; i < RS_BINS; i += 64) {
+        const int32_t c = cnt[i];
+        hist[(int64_t)i * chunks + blockIdx.x] = c;
+        if (c) atomicAdd(&totals[i], c);
+    }
 }
 
-// in-place exclusive scan of m int32 by one workgroup of 1024 threads (m = RS_BINS * chunks: 89 k entries for the
-// stride-1 map of four bench scans)
-__global__ __launch_bounds__(1024) void k_rs_scan(int32_t *__restrict__ a, int64_t m) {
-    __shared__ int32_t wsum[16];
-    __shared__ int32_t carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < m; base += 4096) {
-        // four consecutive entries per thread
-        const int64_t i0 = base + (int64_t)tid * 4;
-        int32_t v[4];
+// one wavefront per digit d: hist[d][*] becomes the exclusive scan of the digit's chunk counts, offset by the number of
+// keys with a smaller digit (the sum of totals[0 .. d)) -- the global position of the first key of (digit, chunk)
+__global__ __launch_bounds__(64) void k_rs_scan(int32_t *__restrict__ hist, const int32_t *__restrict__ totals, int chunks) {
+    const int d = blockIdx.x, lane = threadIdx.x;
+    int32_t before = 0;
+    for (int i = lane; i < d; i += 64) before += totals[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (i0 + j < m) ? a[i0 + j] : 0;
-        const int32_t mine = v[0] + v[1] + v[2] + v[3];
-        int32_t inc = mine;
+    for (int s = 32; s >= 1; s >>= 1) before += __shfl_xor(before, s);
+    int32_t *row = hist + (int64_t)d * chunks;
+    int32_t run = before;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int32_t v = c < chunks ? row[c] : 0;
+        int32_t inc = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int32_t o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
+        for (int s = 1; s < 64; s <<= 1) {
+            const int32_t o = __shfl_up(inc, s);
+            if (lane >= s) inc += o;
         }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int32_t before = carry;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        int32_t run = before + inc - mine;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < m) a[i0 + j] = run;
-            run += v[j];
-        }
-        __syncthreads();
-        if (tid == 1023) carry = before + inc;
-        __syncthreads();
+        if (c < chunks) row[c] = run + inc - v;
+        run += __shfl(inc, 63);
     }
 }
 
@@ -145,11 +146,20 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t *__restrict__ 
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
     const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int64_t i0 = lo; i0 < hi; i0 += 64) {
-        const int64_t i = i0 + lane;
+    uint32_t kreg[RS_CHUNK / 64];
+    int32_t vreg[RS_CHUNK / 64];
+#pragma unroll
+    for (int r = 0; r < RS_CHUNK / 64; ++r) {
+        const int64_t i = lo + 64 * r + lane;
+        kreg[r] = keys[i < hi ? i : hi - 1];
+        vreg[r] = vals[i < hi ? i : hi - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_CHUNK / 64; ++r) {
+        const int64_t i = lo + 64 * r + lane;
         const bool live = i < hi;
-        const uint32_t key = live ? keys[i] : 0u;
-        const int32_t val = live ? vals[i] : 0;
+        const uint32_t key = kreg[r];
+        const int32_t val = vreg[r];
         const uint32_t d = (key >> shift) & (RS_BINS - 1);
         uint64_t peers = __ballot(live);
 #pragma unroll
@@ -176,16 +186,22 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(64) void k_os_tile_order(const uint32_t *__restrict__ wave_masks, int n_tiles,
                                                       int32_t *__restrict__ tile_order) {
     __shared__ int32_t cur[128];
+    __shared__ uint8_t s_key[OS_TILE_ORDER_LDS];    // the tiles' keys (one coalesced 16-byte load per tile), if they fit
     const int lane = threadIdx.x;
     cur[lane] = 0;
     cur[lane + 64] = 0;
     __syncthreads();
-    auto key_of = [&](int t) {
-        const int w = __popc(wave_masks[4 * t]) + __popc(wave_masks[4 * t + 1]) + __popc(wave_masks[4 * t + 2]) +
-                      __popc(wave_masks[4 * t + 3]);
-        return 127 - w;     // w <= 4 * 27
+    const bool in_lds = n_tiles <= OS_TILE_ORDER_LDS;
+    auto key_global = [&](int t) {
+        const uint4 m = reinterpret_cast<const uint4 *>(wave_masks)[t];
+        return 127 - (__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));     // blocks <= 4 * 27
     };
-    for (int t = lane; t < n_tiles; t += 64) atomicAdd(&cur[key_of(t)], 1);
+    auto key_of = [&](int t) { return in_lds ? (int)s_key[t] : key_global(t); };
+    for (int t = lane; t < n_tiles; t += 64) {
+        const int k = key_global(t);
+        if (in_lds) s_key[t] = (uint8_t)k;
+        atomicAdd(&cur[k], 1);
+    }
     __syncthreads();
     if (lane == 0) {
         int run = 0;
@@ -224,7 +240,7 @@ static int64_t rs_chunks(int64_t n) { return cdiv64(n, RS_CHUNK); }
 // bytes of workspace lidog_kernel_map_sorted needs for a map of n rows
 extern "C" int64_t lidog_kernel_map_sorted_ws(int64_t n) {
     if (n <= 0) return 256;
-    return 256 + 4 * 4 * n + 4 * RS_BINS * rs_chunks(n) + 4096;
+    return 256 + 4 * 4 * n + 4 * RS_BINS * (rs_chunks(n) + 4) + 4096;
 }
 
 // perm [pad128(n)] int32: the rows in sorted order (-1 behind the last one); wave_masks [pad128(n) / 32] uint32: the OR
@@ -247,6 +263,7 @@ extern "C" int lidog_kernel_map_sorted(const int32_t *nbr, int64_t n, int32_t K,
     uint32_t *masks = (uint32_t *)p;              p += 4 * n;
     int32_t *hist = (int32_t *)p;
     const int chunks = (int)rs_chunks(n);
+    int32_t *totals = hist + (int64_t)RS_BINS * chunks;      // [3][RS_BINS], one row per pass (zeroed once)
     const int passes = (K + RS_BITS - 1) / RS_BITS;
     // the pairs ping-pong between (keys, a) and (keys_out, b); the row ids start where an odd / even number of passes
     // leaves them in `perm`
@@ -254,10 +271,12 @@ extern "C" int lidog_kernel_map_sorted(const int32_t *nbr, int64_t n, int32_t K,
     k_os_bitpos<<<1, 32, 0, st>>>(k_off, K, pos);
     k_os_keys<<<(unsigned)cdiv64(n, 256), 256, 0, st>>>(nbr, n, K, pos, keys, va, masks);
     uint32_t *ka = keys, *kb = keys_out;
+    LIDOG_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int32_t) * RS_BINS * passes, st));
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * RS_BITS;
-        k_rs_hist<<<chunks, 64, 0, st>>>(ka, n, shift, chunks, hist);
-        k_rs_scan<<<1, 1024, 0, st>>>(hist, (int64_t)RS_BINS * chunks);
+        int32_t *tot = totals + pass * RS_BINS;
+        k_rs_hist<<<chunks, 64, 0, st>>>(ka, n, shift, chunks, hist, tot);
+        k_rs_scan<<<RS_BINS, 64, 0, st>>>(hist, tot, chunks);
         k_rs_scatter<<<chunks, 64, 0, st>>>(ka, va, n, shift, chunks, hist, kb, vb);
         uint32_t *tk = ka; ka = kb; kb = tk;
         int32_t *tv = va; va = vb; vb = tv;
