@@ -534,8 +534,11 @@ int lidog_trunk_forward(const int64_t *convs, const double *conv_f, int32_t n_co
                         int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs,
                         const int64_t *level_rows, const int64_t *ext, void *arena, int64_t arena_bytes,
                         void *scratch, int64_t scratch_bytes, int64_t *rec, int64_t *need /*[2]*/, int32_t dry,
-                        const int64_t *dp /*[12] or NULL*/, void *stream);
-/* lane: second stream for the weight gradients (NULL = in line), forked behind each data gradient's GEMM
+                        const int64_t *dp /*[12] or NULL*/, void *stream, void *lane /* or NULL */);
+/* forward, lane: second stream (NULL = everything in line): the 1x1 downsample convolution + BatchNorm of a layer's first
+ * block (minkunet_bev.py:414-420) runs on it next to conv1 / conv2 of that block and is joined in front of the residual add
+ * (local BatchNorm only; same results).  Its scratch comes from the arena, so dry and real calls must pass the same lane.
+ * backward, lane: second stream for the weight gradients (NULL = in line), forked behind each data gradient's GEMM
  * (wgrad_first = 0) or before it; joined into `stream` before the call returns. */
 int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_convs, const int64_t *maps,
                          int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs, int32_t n_bufs,

@@ -124,7 +124,7 @@ SIGNATURES = {
     "lidog_trunk_gemm_timing": [_i32],
     "lidog_trunk_gemm_timing_read": [_p],
     "lidog_trunk_work_read": [_p],
-    "lidog_trunk_forward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p, _p],
+    "lidog_trunk_forward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p, _p, _p],
     "lidog_trunk_backward": [_p, _p, _i32, _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
                              _i64, _p, _p, _i32, _i32, _p, _p, _p],
 }

@@ -11,6 +11,8 @@
 // from the caller: `arena` (activations that live until backward), `garena` (gradients; never reused inside one
 // backward pass, so the weight gradients running on the lane stream may read them at any time), `scratch` (product
 // rows, reduction workspaces: main stream only), `lane_scratch` (weight-gradient partial slabs: lane stream only).
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
@@ -207,6 +209,12 @@ inline const int32_t *tile_row(const int64_t *m, int r) { return P<const int32_t
 //   2 = ReLU masks of the BatchNorm + residual + ReLU layers kept as bits (backward reads 1/32 of the saved output)
 //   4 = BatchNorm + ReLU between the two convolutions of a block applied in the second one's staging (in_bn_of below)
 int g_fusions = 7;
+// the downsample branch of a layer's first block on the second stream in the forward pass (A/B: LIDOG_SIDE_FORWARD=0)
+int g_side_forward = [] {
+    const char *e = getenv("LIDOG_SIDE_FORWARD");
+    return (e && e[0] == '0') ? 0 : 1;
+}();
+enum { SIDE_EVENT0 = 3000 };   // events of the forward pass's lane forks / joins, behind everything the backward pass uses
 
 // The BatchNorm + ReLU of op o needs no pass of its own when its output has exactly one reader and that reader is a 3^3
 // convolution + BatchNorm on the matrix-core kernels (conv1 -> BN -> ReLU -> conv2 of a BasicBlock): the reader takes
@@ -307,7 +315,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                                    int32_t n_maps, const int64_t *ops, int32_t n_ops, const int64_t *bufs,
                                    int32_t n_bufs, const int64_t *level_rows, const int64_t *ext, void *arena,
                                    int64_t arena_bytes, void *scratch, int64_t scratch_bytes, int64_t *rec,
-                                   int64_t *need, int32_t dry, const int64_t *dp_desc, void *stream) {
+                                   int64_t *need, int32_t dry, const int64_t *dp_desc, void *stream, void *lane) {
     Ctx ctx{convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows, ext, dry != 0};
     Dp dp{dp_desc};
     if (int rc = check_tables(ctx, false)) return rc;
@@ -316,7 +324,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         // sizes first: nothing is launched into an arena that is too small
         int64_t want[2];
         if (int rc = lidog_trunk_forward(convs, conv_f, n_convs, maps, n_maps, ops, n_ops, bufs, n_bufs, level_rows,
-                                         ext, nullptr, 0, nullptr, 0, rec, want, 1, dp_desc, stream))
+                                         ext, nullptr, 0, nullptr, 0, rec, want, 1, dp_desc, stream, lane))
             return rc;
         LIDOG_REQUIRE(arena && scratch && want[0] <= arena_bytes && want[1] <= scratch_bytes,
                       "trunk: forward needs %lld B of arena and %lld B of scratch, got %lld / %lld", (long long)want[0],
@@ -354,6 +362,16 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         float eps, mom;
     };
     const bool sync = dp.sync_bn();
+    // The 1x1 downsample convolution + BatchNorm of a layer's first block (resnet_block.py:8-56; minkunet_bev.py:414-420)
+    // reads the block input and is read again only by the residual add behind conv2: it runs on the second stream (idle in
+    // the forward pass), next to conv1 / conv2 of its block.  `cur` / `scp`: the stream and the scratch allocator the two
+    // lambdas below launch on -- the launch stream and the per-op scratch, or the lane and the ARENA (the per-op scratch is
+    // recycled by the launch stream's next op while the lane may still be reading).
+    void *cur = stream;
+    Bump *scp = &sc;
+    hipEvent_t *side_events = nullptr;
+    int n_side = 0;
+    std::vector<hipEvent_t> join_of(n_bufs, nullptr);     // buffer -> event after which its lane-made contents are complete
     // buffers whose BatchNorm + ReLU is applied by their reader (fusion 4): filled when the producer has run
     std::vector<InBnArgs> lazy(n_bufs, InBnArgs{nullptr, nullptr, nullptr, nullptr, nullptr});
     // sums_at: where this layer's (sum x, sum x^2, rows) go when they are part of a joint message, else NULL
@@ -388,7 +406,7 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         }
         float *rm = P<float>(c[TC_BNRM]), *rv = P<float>(c[TC_BNRV]);
         double *sums = nullptr;
-        if (bn) sums = sums_at ? sums_at : (double *)sc.take((2 * Cout + 1) * 8);
+        if (bn) sums = sums_at ? sums_at : (double *)scp->take((2 * Cout + 1) * 8);
         // local BatchNorm: the reduction's last kernel finalises mean / invstd / running statistics; SyncBatchNorm:
         // sums and row count only, finalised after the all-reduce
         float *f_mean = sync ? nullptr : mean, *f_invstd = sync ? nullptr : invstd;
@@ -399,16 +417,16 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         const bool os = kind == KIND_K3 && m[TM_PERM] && m[TM_WMASK] && m[TM_ORDER] && m[TM_NBR] && m[TM_NIN] == m[TM_NOUT] &&
                         Cin % 32 == 0 && Cout % 32 == 0 && lidog_get_sparse_core() == 1;
         if (os && bn) {
-            double *ws = (double *)sc.take(lidog_sconv_os_stats_ws(n, Cout) * 8);
+            double *ws = (double *)scp->take(lidog_sconv_os_stats_ws(n, Cout) * 8);
             if (in_bn)
                 TRY(lidog_sconv_os_stats_in_bn(in_bn->pre, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
                                                P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, bias, Cin,
                                                Cout, pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv,
-                                               in_bn->mean, in_bn->invstd, in_bn->w, in_bn->b, 1, stream));
+                                               in_bn->mean, in_bn->invstd, in_bn->w, in_bn->b, 1, cur));
             else
             TRY(lidog_sconv_os_stats(x, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
                                      P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, bias, Cin, Cout,
-                                     pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
+                                     pre, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, cur));
             stats_done = true;
             if (g_timing && !ctx.dry) {
                 g_work[4] += 1;
@@ -417,21 +435,21 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         } else if (os) {
             TRY(lidog_sconv_os(x, P<const int32_t>(m[TM_NBR]), n, K, P<const int32_t>(m[TM_PERM]),
                                P<const uint32_t>(m[TM_WMASK]), P<const int32_t>(m[TM_ORDER]), W, 0, bias, nullptr, Cin,
-                               Cout, pre, stream));
+                               Cout, pre, cur));
         } else if (kind == KIND_K3 || kind == KIND_DOWN) {
             // gathered GEMM into product rows, per-row reduction (+ BatchNorm statistics in its epilogue)
-            float *T = (float *)sc.take(m[TM_P] * Cout * 4);
+            float *T = (float *)scp->take(m[TM_P] * Cout * 4);
             if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_IN]), W, nullptr, Cin, Cout, T,
-                              nullptr, stream, kind == KIND_K3 ? in_bn : nullptr))
+                              nullptr, cur, kind == KIND_K3 ? in_bn : nullptr))
                 return rc;
             const int32_t *rp = P<const int32_t>(m[TM_RP_OUT]), *rl = P<const int32_t>(m[TM_RL_OUT]);
             if (bn) {
-                double *ws = (double *)sc.take(lidog_sconv_reduce_stats_ws(n, Cout) * 8);
+                double *ws = (double *)scp->take(lidog_sconv_reduce_stats_ws(n, Cout) * 8);
                 TRY(lidog_sconv_reduce_rows_stats(T, rp, rl, n, Cout, bias, pre, sums, ws, (double)n, f_eps, f_mom,
-                                                      f_mean, f_invstd, f_rm, f_rv, stream));
+                                                      f_mean, f_invstd, f_rm, f_rv, cur));
                 stats_done = true;
             } else {
-                TRY(lidog_sconv_reduce_rows(T, rp, rl, n, Cout, bias, nullptr, pre, stream));
+                TRY(lidog_sconv_reduce_rows(T, rp, rl, n, Cout, bias, nullptr, pre, cur));
             }
             if (g_timing && !ctx.dry) {
                 g_work[2] += 1;
@@ -440,17 +458,17 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         } else if (kind == KIND_UP) {
             // transposed 2^3 stride 2: every fine row has exactly one pair, the GEMM scatters straight into the output
             if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), P<const int32_t>(m[TM_PAIR_OUT]), W, bias, Cin, Cout, pre,
-                              P<const int32_t>(m[TM_PAIR_IN]), stream))
+                              P<const int32_t>(m[TM_PAIR_IN]), cur))
                 return rc;
         } else if (kind == KIND_1X1) {
-            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), nullptr, W, bias, Cin, Cout, pre, nullptr, stream)) return rc;
+            if (int rc = gemm(ctx, m, x, ctx.rows((int)op[TO_IN]), nullptr, W, bias, Cin, Cout, pre, nullptr, cur)) return rc;
         } else {
-            TRY(lidog_sconv_cin1(x, P<const int32_t>(m[TM_NBR]), W, bias, n, K, Cout, pre, stream));
+            TRY(lidog_sconv_cin1(x, P<const int32_t>(m[TM_NBR]), W, bias, n, K, Cout, pre, cur));
         }
         if (bn && !stats_done) {
             int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
-            double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
-            TRY(lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, stream));
+            double *ws = wsn ? (double *)scp->take(wsn * 8) : nullptr;
+            TRY(lidog_bn_stats(pre, n, Cout, 1, sums, ws, (double)n, f_eps, f_mom, f_mean, f_invstd, f_rm, f_rv, cur));
         }
         pd = Pending{o, op, c, pre, mean, invstd, y, bits, sums, n, Cout, eps, mom};
         return 0;
@@ -458,12 +476,16 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
     auto bn_part = [&](const Pending &pd) -> int {
         const int64_t *op = pd.op, *c = pd.c;
         const float *res = op[TO_RES] >= 0 ? bp[op[TO_RES]] : nullptr;
+        if (res && join_of[op[TO_RES]] && !ctx.dry) {   // the residual branch was made on the lane
+            LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)cur, join_of[op[TO_RES]], 0));
+            join_of[op[TO_RES]] = nullptr;
+        }
         if (in_bn_reader(ctx, pd.o) >= 0) {
             // no apply pass: the one reader of this output normalises the raw rows as it gathers them.  SyncBatchNorm:
             // mean / invstd / running statistics from the all-reduced sums (the apply pass would have derived them)
             if (sync)
                 TRY(lidog_bn_finalize(pd.sums, -1.0, pd.Cout, pd.eps, pd.mom, pd.mean, pd.invstd, P<float>(c[TC_BNRM]),
-                                      P<float>(c[TC_BNRV]), stream));
+                                      P<float>(c[TC_BNRV]), cur));
             lazy[op[TO_OUT]] = InBnArgs{pd.pre, pd.mean, pd.invstd, P<const float>(c[TC_BNW]), P<const float>(c[TC_BNB])};
             return 0;
         }
@@ -471,11 +493,11 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                       // pass, one launch
             TRY(lidog_bn_apply_sync(pd.pre, pd.n, pd.Cout, pd.sums, pd.eps, pd.mom, pd.mean, pd.invstd,
                                     P<float>(c[TC_BNRM]), P<float>(c[TC_BNRV]), P<const float>(c[TC_BNW]),
-                                    P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, stream));
+                                    P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, cur));
             return 0;
         }
         TRY(lidog_bn_apply_bits(pd.pre, pd.n, pd.Cout, 1, pd.mean, pd.invstd, P<const float>(c[TC_BNW]),
-                                    P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, stream));
+                                    P<const float>(c[TC_BNB]), res, (int32_t)op[TO_RELU], pd.y, pd.bits, cur));
         return 0;
     };
     for (int o = 0; o < n_ops; ++o) {
@@ -503,11 +525,48 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             ++o;
             continue;
         }
+        // the block's downsample branch first, on the lane (local BatchNorm only: under SyncBatchNorm its statistics travel
+        // in conv1's message, above)
+        const bool side = lane && !sync && g_side_forward && op[TO_TYPE] == OP_CONVBN && op[TO_FOLD] && nx &&
+                          nx[TO_TYPE] == OP_CONVBN && nx[TO_IN] == op[TO_IN] && nx[TO_RES] < 0 &&
+                          convs[nx[TO_CONV] * TC_COLS + TC_KIND] == KIND_1X1 && n_side < 16;
+        if (side) {
+            hipEvent_t e_fork = nullptr, e_join = nullptr;
+            if (!ctx.dry) {
+                if (!side_events) {
+                    side_events = event_pool(SIDE_EVENT0 + 32);
+                    LIDOG_REQUIRE(side_events, "trunk: cannot create events");
+                    side_events += SIDE_EVENT0;
+                }
+                e_fork = side_events[2 * n_side];
+                e_join = side_events[2 * n_side + 1];
+                LIDOG_CHECK_HIP(hipEventRecord(e_fork, (hipStream_t)stream));
+                LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)lane, e_fork, 0));
+            }
+            ++n_side;
+            Pending pd2;
+            cur = lane;
+            scp = &ar;
+            int rc = conv_part(o + 1, nullptr, pd2);
+            if (!rc) rc = bn_part(pd2);
+            cur = stream;
+            scp = &sc;
+            if (rc) return rc;
+            if (!ctx.dry) {
+                LIDOG_CHECK_HIP(hipEventRecord(e_join, (hipStream_t)lane));
+                join_of[nx[TO_OUT]] = e_join;
+            }
+        }
         if (int rc = conv_part(o, nullptr, pd)) return rc;
         if (op[TO_TYPE] != OP_CONVBN) continue;
         if (sync) TRY(dp.allreduce_f64(pd.sums, 2 * pd.Cout + 1, stream));
         if (int rc = bn_part(pd)) return rc;
+        if (side) ++o;     // the downsample op has been done
     }
+    // nothing made on the lane is left unjoined (every downsample output is a residual above; belt and braces)
+    if (!ctx.dry)
+        for (int b = 0; b < n_bufs; ++b)
+            if (join_of[b]) LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, join_of[b], 0));
     need[0] = ar.peak;
     need[1] = sc.peak;
     return 0;

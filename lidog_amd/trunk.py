@@ -467,7 +467,12 @@ class _TrunkFn(torch.autograd.Function):
                 run.ext.ctypes.data)
         coll = run.coll
         dp = coll.ptr() if coll is not None else None
-        call("lidog_trunk_forward", *args, None, 0, None, 0, run.rec.ctypes.data, need.ctypes.data, 1, dp)
+        # the second stream of the backward pass is idle in the forward pass: the downsample branches of the layers' first
+        # blocks run on it (csrc/trunk.hip); `call_on` appends it behind the launch stream
+        lane = ME._WgradLane.get(dev) if ME._WgradLane.active() else None
+        lane_raw = lane.raw if lane is not None else None
+        call_on(lane_raw, "lidog_trunk_forward", *args, None, 0, None, 0, run.rec.ctypes.data, need.ctypes.data, 1, dp,
+                _lib.stream())
         arenas = run.arenas
         owner = arenas.fwd_owner() if arenas.fwd_owner is not None else None
         if owner is not None and not owner.done:
@@ -480,8 +485,8 @@ class _TrunkFn(torch.autograd.Function):
         if coll is not None:
             coll.regions = (scratch,)
         try:
-            call("lidog_trunk_forward", *args, arena.data_ptr(), arena.numel(), scratch.data_ptr(), scratch.numel(),
-                 run.rec.ctypes.data, need.ctypes.data, 0, dp)
+            call_on(lane_raw, "lidog_trunk_forward", *args, arena.data_ptr(), arena.numel(), scratch.data_ptr(),
+                    scratch.numel(), run.rec.ctypes.data, need.ctypes.data, 0, dp, _lib.stream())
         except RuntimeError:
             if coll is not None:
                 coll.check()

@@ -77,7 +77,7 @@ def _dry(prog, levels, ext_grad, lane=True):
     done = np.zeros(len(convs), np.int32)
     common = (convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps), prog.ops.ctypes.data,
               len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs), lv.ctypes.data, ext.ctypes.data)
-    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need_f.ctypes.data, 1, None, None)
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need_f.ctypes.data, 1, None, None, None)
     assert rc == 0, L.lidog_last_error()
     eg = np.array(ext_grad, np.int64)
     rc = L.lidog_trunk_backward(*common, eg.ctypes.data, None, rec.ctypes.data, None, 0, None, 0, None, 0,
@@ -153,10 +153,10 @@ def test_data_parallel_descriptor_is_checked_and_planned(prog):
     rec, need = np.zeros(prog.n_rec, np.int64), np.zeros(2, np.int64)
     dp = np.zeros(12, np.int64)
     dp[0] = 1
-    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1, dp.ctypes.data, None)
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1, dp.ctypes.data, None, None)
     assert rc != 0 and b"communicator or a callback" in L.lidog_last_error()
     dp[2] = 4096       # a callback address: never called in a dry run
-    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1, dp.ctypes.data, None)
+    rc = L.lidog_trunk_forward(*common, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1, dp.ctypes.data, None, None)
     assert rc == 0, L.lidog_last_error()
     assert need[0] == need_f[0] and need_f[1] <= need[1] <= 1.1 * need_f[1]   # conv1 and the downsample share one pass
     dp2 = np.zeros(12, np.int64)
@@ -177,7 +177,7 @@ def test_real_run_refuses_regions_that_are_too_small(prog):
     need = np.zeros(2, np.int64)
     # one byte short of the plan: refused before anything is launched (no GPU is touched on this path)
     rc = L.lidog_trunk_forward(*common, ctypes.c_void_p(4096), int(need_f[0]) - 1, ctypes.c_void_p(4096), int(need_f[1]),
-                               rec.ctypes.data, need.ctypes.data, 0, None, None)
+                               rec.ctypes.data, need.ctypes.data, 0, None, None, None)
     assert rc != 0 and b"arena" in L.lidog_last_error()
 
 
@@ -193,7 +193,7 @@ def test_tables_are_checked(prog):
     rc = L.lidog_trunk_forward(convs.ctypes.data, conv_f.ctypes.data, len(convs), maps.ctypes.data, len(maps),
                                prog.ops.ctypes.data, len(prog.ops), prog.bufs.ctypes.data, len(prog.bufs),
                                lv.ctypes.data, ext.ctypes.data, None, 0, None, 0, rec.ctypes.data, need.ctypes.data, 1,
-                               None, None)
+                               None, None, None)
     assert rc != 0 and b"rows" in L.lidog_last_error()
 
 
