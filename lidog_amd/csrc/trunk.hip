@@ -215,6 +215,27 @@ int g_side_forward = [] {
     return (e && e[0] == '0') ? 0 : 1;
 }();
 enum { SIDE_EVENT0 = 3000 };   // events of the forward pass's lane forks / joins, behind everything the backward pass uses
+// ... and in the backward pass the same branch (BatchNorm backward + 1x1 data gradient of the downsample convolution) runs
+// on a third stream of this library's, between the residual add's gradient and the block input's (A/B: LIDOG_SIDE_BACKWARD=0)
+int g_side_backward = [] {
+    const char *e = getenv("LIDOG_SIDE_BACKWARD");
+    return (e && e[0] == '0') ? 0 : 1;
+}();
+enum { SIDE_BWD_EVENT0 = SIDE_EVENT0 + 64 };
+
+hipStream_t side_stream() {
+    static std::mutex lock;
+    static std::vector<std::pair<int, hipStream_t>> streams;     // one per device this process drives
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> guard(lock);
+    for (auto &p : streams)
+        if (p.first == dev) return p.second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    streams.emplace_back(dev, st);
+    return st;
+}
 
 // The BatchNorm + ReLU of op o needs no pass of its own when its output has exactly one reader and that reader is a 3^3
 // convolution + BatchNorm on the matrix-core kernels (conv1 -> BN -> ReLU -> conv2 of a BasicBlock): the reader takes
@@ -687,12 +708,57 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     }
     // BatchNorm-backward sums of op o already produced by the reduction that completed its output gradient
     std::vector<double *> bwd_sums(n_ops, nullptr);
+    // Side branch: the downsample convolution of a layer's first block (1x1 + BatchNorm, no ReLU; its output is only the
+    // residual of conv2's BatchNorm) has its backward -- BatchNorm reduce + apply, 1x1 data gradient -- on a third stream,
+    // from the moment conv2's BatchNorm backward has written the residual's gradient until conv1's data gradient adds the
+    // branch's contribution to the block input's gradient.  Local BatchNorm, no gradient buckets (their events watch the
+    // launch stream and the lane only).  Same kernels, same arguments: same bits.
+    const bool side_on = g_side_backward && lane && !sync && !dp.buckets();
+    hipStream_t side_st = nullptr;
+    hipEvent_t *side_ev = nullptr;
+    int n_side = 0;
+    std::vector<int> is_side(n_ops, 0);
+    if (side_on)
+        for (int o = 1; o < n_ops; ++o) {
+            const int64_t *op = ops + (int64_t)o * TO_COLS, *pv = ops + (int64_t)(o - 1) * TO_COLS;
+            if (op[TO_TYPE] == OP_CONVBN && pv[TO_TYPE] == OP_CONVBN && pv[TO_FOLD] && pv[TO_IN] == op[TO_IN] &&
+                op[TO_RES] < 0 && !op[TO_RELU] && convs[op[TO_CONV] * TC_COLS + TC_KIND] == KIND_1X1 &&
+                bufs[op[TO_OUT] * TB_COLS + TB_EXT] < 0 && bufs[op[TO_IN] * TB_COLS + TB_EXT] != 0)
+                is_side[o] = 1;
+        }
+    std::vector<hipEvent_t> res_ready(n_bufs, nullptr), join_evt(n_bufs, nullptr);
+    std::vector<char> res_ok(n_bufs, 0);     // the buffer's gradient is one residual gradient (decided alike in dry runs)
+    hipEvent_t side_last = nullptr;
+    auto join_side = [&](int b) -> int {      // the launch stream is about to read what the side branch wrote for buffer b
+        if (join_evt[b] && !ctx.dry) LIDOG_CHECK_HIP(hipStreamWaitEvent(main_st, join_evt[b], 0));
+        join_evt[b] = nullptr;
+        return 0;
+    };
     for (int o = n_ops - 1; o >= 0; --o) {
         const int64_t *op = ops + (int64_t)o * TO_COLS;
         const int64_t *r = rec + (int64_t)o * REC_COLS;
         sc.reset();
         const int out_b = (int)op[TO_OUT], in_b = (int)op[TO_IN];
         if (gs[out_b] == 0) continue;  // nothing reached this output: no gradients below it on this branch
+        if (int rc = join_side(out_b)) return rc;
+        // this op on the side stream?  (its output gradient is exactly one BatchNorm's residual gradient, and nothing has
+        // reached the block input yet: the branch is the first contributor there, no add kernel)
+        const bool side_op = is_side[o] && res_ok[out_b] && gs[in_b] == 0 && n_side < 16;
+        void *cur = stream;
+        Bump *scp = &sc;
+        if (side_op) {
+            if (!ctx.dry) {
+                if (!side_st) {
+                    side_st = side_stream();
+                    side_ev = event_pool(SIDE_BWD_EVENT0 + 64);
+                    LIDOG_REQUIRE(side_st && side_ev, "trunk: cannot create the side stream");
+                    side_ev += SIDE_BWD_EVENT0;
+                }
+                LIDOG_CHECK_HIP(hipStreamWaitEvent(side_st, res_ready[out_b], 0));
+                cur = (void *)side_st;
+            }
+            scp = &ga;      // per-op scratch is recycled by the launch stream's next op
+        }
         if (op[TO_TYPE] == OP_CAT) {
             int a = in_b, b = (int)op[TO_B];
             float *ga_ = target(a), *gb_ = target(b);
@@ -718,12 +784,12 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             const float *bnw = P<const float>(c[TC_BNW]), *bnb = P<const float>(c[TC_BNB]);
             double *sums = bwd_sums[o];
             if (!sums) {
-                sums = (double *)sc.take((2 * Cout + 1) * 8);
+                sums = (double *)scp->take((2 * Cout + 1) * 8);
                 int64_t wsn = lidog_bn_reduce_ws(Cout, 1);
-                double *ws = wsn ? (double *)sc.take(wsn * 8) : nullptr;
+                double *ws = wsn ? (double *)scp->take(wsn * 8) : nullptr;
                 TRY(lidog_bn_bwd_reduce_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, sums, ws, (double)n,
                                                  P<float>(c[TC_GBNW]), P<float>(c[TC_GBNB]), mask_from_x ? bnw : nullptr,
-                                                 mask_from_x ? bnb : nullptr, stream));
+                                                 mask_from_x ? bnb : nullptr, cur));
             }
             float *dx = (float *)ga.take(n * Cout * 4);
             float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
@@ -731,9 +797,24 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             if (sync) TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
             TRY(lidog_bn_bwd_apply_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, bnw, sums,
                                              sync ? -1.0 : (double)n, dx, dres, nullptr, nullptr,
-                                             mask_from_x ? bnb : nullptr, stream));
-            if (has_res)
-                if (int rc = commit((int)op[TO_RES], dres)) return rc;
+                                             mask_from_x ? bnb : nullptr, cur));
+            if (has_res) {
+                const int rb = (int)op[TO_RES];
+                const bool first = gs[rb] == 0;
+                if (int rc = commit(rb, dres)) return rc;
+                // the residual branch may start now (if it is a side branch and this was its whole gradient)
+                if (side_on && first && producer[rb] >= 0 && is_side[producer[rb]] && n_side < 16) res_ok[rb] = 1;
+                if (res_ok[rb] && !ctx.dry) {
+                    if (!side_ev) {
+                        side_st = side_stream();
+                        side_ev = event_pool(SIDE_BWD_EVENT0 + 64);
+                        LIDOG_REQUIRE(side_st && side_ev, "trunk: cannot create the side stream");
+                        side_ev += SIDE_BWD_EVENT0;
+                    }
+                    res_ready[rb] = side_ev[2 * n_side];
+                    LIDOG_CHECK_HIP(hipEventRecord(res_ready[rb], main_st));
+                }
+            }
             gout = dx;
         }
         // ---- convolution backward (me._SparseConvFn.backward)
@@ -769,19 +850,19 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             int slabs = lidog_sconv_wgrad_slabs(Cin, Cout, n_items);
             int64_t pbytes = (int64_t)(slabs > 1 ? slabs : 1) * Cin * Cout * 4;
             float *partial;
-            void *st = stream;
+            void *st = cur;
             if (lane) {
                 ls.reset();
                 partial = (float *)ls.take(pbytes);
                 if (!ctx.dry) {
                     hipEvent_t ev = events[op[TO_CONV]];
-                    LIDOG_CHECK_HIP(hipEventRecord(ev, main_st));
+                    LIDOG_CHECK_HIP(hipEventRecord(ev, (hipStream_t)cur));
                     LIDOG_CHECK_HIP(hipStreamWaitEvent(lane_st, ev, 0));
                 }
                 st = lane;
                 lane_used = 1;
             } else {
-                partial = (float *)sc.take(pbytes);
+                partial = (float *)scp->take(pbytes);
             }
             if (in_bn.pre)
                 TRY(lidog_sconv_wgrad_in_bn(in_bn.pre, g_in, gout, g_out, P<const int32_t>(c[TC_ITEMS]), n_items,
@@ -801,16 +882,22 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             if (int rc = queue_wgrad()) return rc;
         const bool need_dgrad = bufs[in_b * TB_COLS + TB_EXT] != 0 && kind != KIND_STEM;  // ext slot 0 = input features
         if (need_dgrad) {
+            if (int rc = join_side(in_b)) return rc;    // what a side branch has written to this buffer's gradient
             const float *Wt = P<const float>(c[TC_WT]);
             if (!Wt) {
                 float *w = (float *)ga.take((int64_t)K * Cin * Cout * 4);
-                TRY(lidog_transpose_kernel(P<const float>(c[TC_W]), K, Cin, Cout, w, stream));
+                TRY(lidog_transpose_kernel(P<const float>(c[TC_W]), K, Cin, Cout, w, cur));
                 Wt = w;
             }
             if (kind == KIND_1X1) {
                 float *gx = target(in_b);
-                if (int rc = gemm(ctx, m, gout, n, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, stream)) return rc;
+                if (int rc = gemm(ctx, m, gout, n, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, cur)) return rc;
                 if (int rc = commit(in_b, gx)) return rc;
+                if (side_op && !ctx.dry) {
+                    join_evt[in_b] = side_ev[2 * n_side + 1];
+                    LIDOG_CHECK_HIP(hipEventRecord(join_evt[in_b], side_st));
+                    side_last = join_evt[in_b];
+                }
             } else if (kind == KIND_DOWN) {
                 // every fine (input) row has exactly one pair: the GEMM scatters straight into the gradient
                 float *gx = target(in_b);
@@ -895,8 +982,15 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
         if (!wgrad_done)
             if (int rc = queue_wgrad()) return rc;
         if (c[TC_BIAS] && c[TC_GBIAS]) {
-            double *ws = (double *)sc.take(lidog_colsum_ws(Cout) * 8);
-            TRY(lidog_colsum(gout, n, Cout, P<float>(c[TC_GBIAS]), ws, stream));
+            double *ws = (double *)scp->take(lidog_colsum_ws(Cout) * 8);
+            TRY(lidog_colsum(gout, n, Cout, P<float>(c[TC_GBIAS]), ws, cur));
+        }
+        if (side_op) {
+            if (!ctx.dry && !join_evt[in_b]) {   // no data gradient was asked for: still order the parameter gradients
+                side_last = side_ev[2 * n_side + 1];
+                LIDOG_CHECK_HIP(hipEventRecord(side_last, side_st));
+            }
+            ++n_side;
         }
         // every parameter gradient of this convolution is queued now (kernel: lane or launch stream; bias and BatchNorm
         // gains / biases: launch stream)
@@ -910,6 +1004,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             }
         }
     }
+    if (side_last && !ctx.dry) LIDOG_CHECK_HIP(hipStreamWaitEvent(main_st, side_last, 0));   // BatchNorm gradients of the side ops
     if (lane_used && !ctx.dry) {
         hipEvent_t ev = events[n_convs];
         LIDOG_CHECK_HIP(hipEventRecord(ev, lane_st));
