@@ -117,6 +117,12 @@ int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t mark
 int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
                      const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles,
                      int32_t Cin, int32_t Cout, float *T, const int32_t *scatter, void *stream);
+/* T = addend + product of the same gathered GEMM, narrow inputs only (Cin <= 8, Cout % 4 == 0): the data gradient of the
+ * classifier `final` (minkunet_bev.py:118-123, 7 -> 96) lands on rows that already hold the BEV head's gradient.  Same
+ * bits as lidog_sconv_gemm + lidog_add(addend, product).  Returns 3 for other shapes (nothing launched). */
+int lidog_sconv_gemm_addend(const float *A, const int32_t *gather, const float *B, const int32_t *tile_k,
+                            const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles, int32_t Cin,
+                            int32_t Cout, const float *addend, float *T, const int32_t *scatter, void *stream);
 
 /* out[o][:] = sum over k ascending of T[pos[k*n + o]][:] (skipping -1), plus bias if not NULL.
  * The gather->GEMM->scatter-add order of the ME CPU algorithm, without atomics. */

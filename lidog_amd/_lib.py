@@ -26,6 +26,7 @@ SIGNATURES = {
     "lidog_kernel_map_bits": [_p, _i64, _p, _p, _i64, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_kernel_map_pairs": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
     "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_gemm_addend": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_stats_ws": [_i64, _i32],
     "lidog_sconv_reduce_stats": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],

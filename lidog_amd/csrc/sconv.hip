@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_cin8(const float *__restrict
                                                          const int32_t *__restrict__ tile_row0,
                                                          const int32_t *__restrict__ tile_rows, int Cin, int Cout,
                                                          float *__restrict__ T,
-                                                         const int32_t *__restrict__ scatter) {
+                                                         const int32_t *__restrict__ scatter,
+                                                         const float *__restrict__ addend) {
     extern __shared__ float s_w[];  // [Cin][Cout]
     const int tile = blockIdx.x;
     const int k = tile_k[tile], row0 = tile_row0[tile], rows = tile_rows[tile];
@@ -255,6 +256,10 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_cin8(const float *__restrict
         const int r = e / C4, c4 = e - r * C4;
         const int src = gather ? gather[row0 + r] : (row0 + r);
         const float *x = A + (size_t)src * Cin;
+        const size_t dst = scatter ? (size_t)scatter[row0 + r] : (size_t)(row0 + r);
+        // `addend + product`, the operand order of lidog_add(addend, product): the same bits as the separate pass
+        float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (addend) ad = *reinterpret_cast<const float4 *>(&addend[dst * Cout + c4 * 4]);
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ci = 0; ci < Cin; ++ci) {
             const float xv = x[ci];
@@ -267,9 +272,28 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_cin8(const float *__restrict
         if (bias) {
             t.x += bias[c4 * 4]; t.y += bias[c4 * 4 + 1]; t.z += bias[c4 * 4 + 2]; t.w += bias[c4 * 4 + 3];
         }
-        const size_t dst = scatter ? (size_t)scatter[row0 + r] : (size_t)(row0 + r);
+        if (addend) {
+            t.x = ad.x + t.x; t.y = ad.y + t.y; t.z = ad.z + t.z; t.w = ad.w + t.w;
+        }
         *reinterpret_cast<float4 *>(&T[dst * Cout + c4 * 4]) = t;
     }
+}
+
+// T = addend + (the gathered GEMM's product), for the narrow-input case (Cin <= 8, Cout % 4 == 0: the classifier's data
+// gradient 7 -> 96, whose result is added to the gradient the BEV head left on the same rows): one pass instead of a
+// product pass and an add pass; the same bits as lidog_sconv_gemm followed by lidog_add(addend, product).  Returns 3
+// (without touching anything) for shapes it does not cover.
+extern "C" int lidog_sconv_gemm_addend(const float *A, const int32_t *gather, const float *B, const int32_t *tile_k,
+                                       const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles, int32_t Cin,
+                                       int32_t Cout, const float *addend, float *T, const int32_t *scatter, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!(Cin >= 1 && Cin <= 8 && Cout % 4 == 0 && Cin * Cout * 4 <= 32 * 1024)) return 3;
+    if (n_tiles == 0) return 0;
+    LIDOG_REQUIRE(A && B && T && addend && tile_k && tile_row0 && tile_rows, "sconv_gemm_addend: null argument");
+    k_sconv_gemm_cin8<<<dim3((unsigned)n_tiles), 256, (size_t)Cin * Cout * sizeof(float), st>>>(
+        A, gather, B, nullptr, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter, addend);
+    LIDOG_LAUNCH_CHECK();
+    return 0;
 }
 
 // The gathered GEMM with the BatchNorm (+ ReLU) of the layer BEFORE applied to the rows as they are gathered: A is that
@@ -321,7 +345,7 @@ extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const flo
         default:
             if (Cin <= 8 && Cout % 4 == 0 && Cin * Cout * 4 <= 32 * 1024)
                 k_sconv_gemm_cin8<<<dim3((unsigned)n_tiles), 256, (size_t)Cin * Cout * sizeof(float), st>>>(
-                    A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter);
+                    A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter, nullptr);
             else if (Cout <= 8 && Cin % 4 == 0 && Cin <= 1024)
                 k_sconv_gemm_cout8<<<dim3((unsigned)n_tiles), 256, (size_t)Cin * 8 * sizeof(float), st>>>(
                     A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, T, scatter);

@@ -889,7 +889,15 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 TRY(lidog_transpose_kernel(P<const float>(c[TC_W]), K, Cin, Cout, w, cur));
                 Wt = w;
             }
-            if (kind == KIND_1X1) {
+            if (kind == KIND_1X1 && Cout <= 8 && Cin % 4 == 0 && gs[in_b] != 0) {
+                // the classifier's data gradient on rows that already hold a gradient (the BEV head's): product and sum
+                // in one pass, the bits of the product pass followed by commit()'s lidog_add
+                float *dst = gs[in_b] == 2 ? gp[in_b] : (float *)ga.take(ctx.bytes(in_b));
+                TRY(lidog_sconv_gemm_addend(gout, nullptr, Wt, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2),
+                                            (int32_t)m[TM_NTILES], Cout, Cin, gp[in_b], dst, nullptr, cur));
+                gp[in_b] = dst;
+                gs[in_b] = 2;
+            } else if (kind == KIND_1X1) {
                 float *gx = target(in_b);
                 if (int rc = gemm(ctx, m, gout, n, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, cur)) return rc;
                 if (int rc = commit(in_b, gx)) return rc;
