@@ -753,7 +753,7 @@ _BITMAP_MIN_ROWS = int(os.environ.get("LIDOG_MAP_BITMAP_MIN_ROWS", "40000"))
 # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X (LIDOG_WGRAD_BLOCKS: A/B runs)
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("LIDOG_WGRAD_BLOCKS", "2048"))
 # the >= 256 x 256 layers (few pairs, 256 KB partial slots): A/B switch
-_WGRAD_WIDE_BLOCKS = int(os.environ.get("LIDOG_WGRAD_WIDE_BLOCKS", str(_WGRAD_TARGET_BLOCKS)))
+_WGRAD_WIDE_BLOCKS = int(os.environ.get("LIDOG_WGRAD_WIDE_BLOCKS", str(_WGRAD_TARGET_BLOCKS // 2)))
 
 
 def _wgrad_chunk(P, Cin, Cout):
