@@ -719,6 +719,10 @@ def main():
                                                  f"over the {PMC_TRAFFIC_TAG} build (scripts/profile_round.sh), "
                                                  "not collected by this run" if traffic is not None else None,
                                "kernel": "k_sconv_gemm_mfma (gathered GEMM of the sparse convolutions, f32 MFMA)",
+                               "note": "launch durations IN the step: since round 5 the forward launches share the chip with "
+                                       "the downsample branches on the second stream and the backward ones with the weight "
+                                       "gradients (DESIGN.md 3a); one-stream durations: "
+                                       f"profiles/{PMC_TRAFFIC_TAG}_kernel_stats_train_bs4_one_stream.csv",
                                "algorithmic_flops_per_launch": s["flops"] / s["launches"],
                                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
                                "avg_launch_us": 1e3 * s["total_ms"] / s["launches"], "launches": s["launches"],
