@@ -461,6 +461,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # stdout carries ONE line, rank 0's JSON.  RCCL prints a version banner to file descriptor 1 when its first
+    # communicator comes up, and other native libraries may do the same: in a distributed run descriptor 1 is pointed at
+    # stderr for the life of the process and the result line is written to the saved descriptor (emit() below).
+    result_fd = None
+    if world > 1 or os.environ.get("LIDOG_BENCH_SINGLE_RANK_DP") == "1":
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(line):
+        if result_fd is None:
+            print(line, flush=True)
+        else:
+            os.write(result_fd, (line + "\n").encode())
     if world != args.gpus:
         # checked before any collective or GPU work: every rank sees the same mismatch and leaves with the same message
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; run "
@@ -780,7 +794,7 @@ def main():
             wh = res["cpu_baseline"].get("whole_host") or {}
             if wh.get("value"):
                 res["gpu_over_cpu_whole_host"] = value / wh["value"]
-        print(json.dumps(res), flush=True)
+        emit(json.dumps(res))
     probe_port = None
     if world > 1 and os.environ.get("LIDOG_BENCH_LAUNCHED_BY_PARENT") != "1" and not peer_error:
         # ranks started by somebody else's launcher (the driver's torch.distributed.run line): there is no parent of ours
