@@ -531,6 +531,11 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
     };
     auto next_offset = [&](uint32_t rem) { return reverse ? 31 - __builtin_clz(rem) : __builtin_ctz(rem); };
 
+    // (Round 5: TWO chunks of gathered rows in flight -- a second set of staging registers, the weight loads of chunk c+1
+    // issued before the row loads of chunk c+2 so that the in-order load counter lets the store of chunk c+1 go ahead;
+    // 194 registers, bit-identical -- measured: 0.382 vs 0.383 ms forward and 0.423 vs 0.413 ms data gradient on the
+    // stride-1 96-channel layer alone, 47.45 / 47.49 vs 47.43 / 47.49 ms in the step.  The 20 % this loop gains without
+    // any global load is not the loads' latency.  Not kept; profiles/r05_ab_os_two_chunks_in_flight.txt.)
     uint32_t rem = tm;
     if (rem != 0) {
         int k_cur = next_offset(rem);
