@@ -236,3 +236,18 @@ def test_bev_head_gradients_are_run_to_run_identical():
         assert torch.equal(a[2][k], b[2][k]), k
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_side_streams_leave_every_parameter_bit_identical_at_bench_size():
+    """csrc/trunk.hip runs the downsample branch of every layer's first block on the second stream (forward) and on a third
+    stream (backward).  Same kernels, same arguments: after 12 optimiser steps on bench scans (bs 2, prefetching, as the
+    bench runs) every parameter and running statistic is bit-identical with the side streams on and off (two child
+    processes; `scripts/soak_side_streams.py`, 80 steps at bs 4 and bs 2 in profiles/r05_soak_side_streams.txt)."""
+    import os
+    import subprocess
+    import sys
+    from helpers import REPO
+    p = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "soak_side_streams.py"), "12", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "bit-identical after 12 steps: True" in p.stdout and p.stdout.count("_TrunkFnBackward") == 2
