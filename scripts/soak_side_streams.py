@@ -1,7 +1,7 @@
 """Soak check of the executor's side streams (csrc/trunk.hip: downsample branches on the second / a third stream): N training
 steps of the bench workload with the side streams on and off in two child processes; every parameter and running statistic
 must be bit-identical afterwards (same kernels, same arguments -- only the streams differ, so any race shows up here).
-    python scripts/soak_side_streams.py [steps] [batch]"""
+    python scripts/soak_side_streams.py [steps] [batch]        (SOAK_DP=1: a one-rank data-parallel step, every collective active)"""
 import hashlib, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -12,8 +12,22 @@ import torch, lidog_amd
 from lidog_amd import synth
 from lidog_amd.trainer import FlatAdam, LiDOGStep
 steps, bs = int(sys.argv[1]), int(sys.argv[2])
+DP = os.environ.get("SOAK_DP") == "1"      # one-rank RCCL group, SyncBatchNorm + gradient buckets active (as LIDOG_BENCH_SINGLE_RANK_DP=1)
+if DP:
+    import socket
+    import torch.distributed as dist
+    import lidog_amd.me as ME
+    from lidog_amd.trainer import GradientBuckets, setup_data_parallel
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ME.MinkowskiSyncBatchNorm.single_rank = GradientBuckets.single_rank = True
 torch.manual_seed(1234)
 model = lidog_amd.MinkUNet34BEV(1, 7, 3, mapping_bound_2d=50.0).cuda().train()
+if DP:
+    model = setup_data_parallel(model)
 step = LiDOGStep(model, FlatAdam(model, lr=1e-3, weight_decay=1e-4))
 batches = [synth.make_batch(range(bs * i, bs * i + bs), "kitti120k", "cuda") for i in range(2)]
 ready = torch.cuda.Event(); ready.record(); torch.cuda.synchronize()
