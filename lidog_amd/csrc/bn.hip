@@ -260,7 +260,12 @@ unsigned *lidog_stats_tickets(hipStream_t stream) {
     auto it = g_ticket_blocks.find(key);
     if (it != g_ticket_blocks.end()) return it->second;
     unsigned *p = nullptr;
-    if (hipMalloc((void **)&p, kTicketBytes) != hipSuccess || hipMemset(p, 0, kTicketBytes) != hipSuccess) {
+    // zeroed IN THE ORDER OF `stream`: hipMemset on device memory is asynchronous to the host and runs on the NULL stream,
+    // which a non-blocking stream does not wait for -- with work queued on the NULL stream the first statistics kernel of a
+    // new stream found garbage tickets, no workgroup saw itself as the last one and the sums were never written (round 5:
+    // the first downsample branch on the side stream, 1 fresh process in 15; scripts/memset_order_probe.py,
+    // tests/test_gpu_ops.py::test_first_statistics_launch_on_a_new_stream_while_the_default_stream_is_busy)
+    if (hipMalloc((void **)&p, kTicketBytes) != hipSuccess || hipMemsetAsync(p, 0, kTicketBytes, stream) != hipSuccess) {
         lidog_set_error("stats tickets: cannot allocate %zu bytes of device memory", kTicketBytes);
         return nullptr;
     }

@@ -275,7 +275,10 @@ extern "C" int lidog_peer_comm_create(int32_t rank, int32_t nranks, int32_t max_
     c->local = (double *)local;
     for (int r = 0; r < nranks; ++r) c->peers[r] = (double *)peer_ptrs[r];
     c->peers[rank] = c->local;
-    if (hipMalloc((void **)&c->err_dev, sizeof(int32_t)) != hipSuccess || hipMemset(c->err_dev, 0, sizeof(int32_t)) != hipSuccess) {
+    // (hipMemset on device memory is asynchronous to the host and ordered on the NULL stream only: wait for it here, the
+    // all-reduce kernels run on whatever stream the communicator is bound to later)
+    if (hipMalloc((void **)&c->err_dev, sizeof(int32_t)) != hipSuccess || hipMemset(c->err_dev, 0, sizeof(int32_t)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
         delete c;
         lidog_set_error("peer_comm_create: cannot allocate the error word");
         return 1;

@@ -382,3 +382,55 @@ def test_in_kernel_statistics_tail_equals_the_separate_finish_kernel(tmp_path):
     # failure the hand-off protocol must exclude) would be off by ~1/workgroups, eleven orders of magnitude more
     for a, b in zip(res["1"], res["0"]):
         assert ((a - b).abs() <= 1e-12 * b.abs() + 1e-12).all(), (a - b).abs().max()
+
+
+def test_first_statistics_launch_on_a_new_stream_while_the_default_stream_is_busy():
+    """Round 5 bug: the ticket words of a stream's statistics tail were zeroed with hipMemset, which is asynchronous to
+    the host and ordered on the NULL stream only; with a backlog on the NULL stream the first reduction on a NEW
+    non-blocking stream started on garbage tickets, no workgroup took itself for the last one, and sums / mean / invstd
+    were never written (first downsample branch of a fresh process on the side stream: zero BatchNorm gradients, 1 in 15).
+    Eight fresh streams, each with its first launch behind a backlog of matrix products on the default stream; checked
+    against the old hipMemset build: fails there (sums stay NaN), passes with hipMemsetAsync on the tickets' own stream."""
+    import ctypes
+    from lidog_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    n, C = 200_000, 96
+    x = torch.randn(n, C, generator=g).cuda()
+    ref = torch.cat([x.double().sum(0), (x.double() ** 2).sum(0)])
+    a = torch.randn(4096, 4096, device="cuda")
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    torch.cuda.synchronize()
+    # fresh device memory comes zero-filled from the driver, which hides the bug: make the runtime's allocator hand out
+    # RECYCLED fragments instead (filled with ones, freed, then taken again by the ticket allocations below)
+    hip = ctypes.CDLL("libamdhip64.so")
+    dirty = []
+    for _ in range(64):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(768)) == 0
+        assert hip.hipMemset(p, 0xFF, ctypes.c_size_t(768)) == 0
+        dirty.append(p)
+    assert hip.hipDeviceSynchronize() == 0
+    for p in dirty[1:-1]:      # the first and the last stay allocated: an empty block would go back to the driver
+        assert hip.hipFree(p) == 0
+    streams = []
+    for _ in range(8):
+        st = torch.cuda.Stream()
+        streams.append(st)
+        sums = torch.full((2 * C + 1,), float("nan"), dtype=torch.float64, device="cuda")
+        mean = torch.full((C,), float("nan"), device="cuda")
+        invstd = torch.full((C,), float("nan"), device="cuda")
+        ws = torch.empty(int(lib.lidog_bn_reduce_ws(C, 1)), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(20):      # ~20 ms of work queued on the default (NULL) stream
+            a @ a
+        _lib.call_on(st.cuda_stream, "lidog_bn_stats", ptr(x), n, C, 1, ptr(sums), ptr(ws), float(n), 1e-5, 0.1,
+                     ptr(mean), ptr(invstd), None, None)
+        st.synchronize()
+        assert torch.isfinite(sums).all() and torch.isfinite(mean).all() and torch.isfinite(invstd).all(), \
+            "the reduction's last workgroup never finished the sums"
+        assert ((sums[:2 * C] - ref).abs() <= 1e-9 * ref.abs() + 1e-9).all()
+        assert float(sums[2 * C]) == n
+        torch.cuda.synchronize()
+    for p in (dirty[0], dirty[-1]):
+        assert hip.hipFree(p) == 0
