@@ -536,8 +536,53 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
                            nx[TO_IN] == op[TO_IN] && convs[nx[TO_CONV] * TC_COLS + TC_KIND] == KIND_1X1;
         if (joint) {
             const int Ca = (int)convs[op[TO_CONV] * TC_COLS + TC_COUT], Cd = (int)convs[nx[TO_CONV] * TC_COLS + TC_COUT];
-            double *msg = (double *)sc.take((int64_t)(2 * Ca + 1 + 2 * Cd + 1) * 8);
+            const int64_t msg_bytes = (int64_t)(2 * Ca + 1 + 2 * Cd + 1) * 8;
+            // the downsample branch on the lane under SyncBatchNorm too: its convolution + statistics next to conv1's, the
+            // joint message all-reduced ON THE LAUNCH STREAM as before (the order of the collectives does not change), its
+            // apply pass back on the lane behind the all-reduce.  The message then lives in the arena (the lane still reads
+            // its half after the launch stream's next op has recycled the per-op scratch).
+            const bool jside = lane && g_side_forward && nx[TO_RES] < 0 && n_side < 16;
+            double *msg = (double *)(jside ? ar.take(msg_bytes) : sc.take(msg_bytes));
             Pending pd2;
+            if (jside) {
+                hipEvent_t *ev = nullptr;   // fork, branch statistics ready, all-reduce done, branch output ready
+                if (!ctx.dry) {
+                    if (!side_events) {
+                        side_events = event_pool(SIDE_EVENT0 + 64);
+                        LIDOG_REQUIRE(side_events, "trunk: cannot create events");
+                        side_events += SIDE_EVENT0;
+                    }
+                    ev = side_events + 4 * n_side;
+                    LIDOG_CHECK_HIP(hipEventRecord(ev[0], (hipStream_t)stream));
+                    LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)lane, ev[0], 0));
+                }
+                ++n_side;
+                cur = lane;
+                scp = &ar;
+                int rc = conv_part(o + 1, msg + 2 * Ca + 1, pd2);
+                cur = stream;
+                scp = &sc;
+                if (rc) return rc;
+                if (!ctx.dry) LIDOG_CHECK_HIP(hipEventRecord(ev[1], (hipStream_t)lane));
+                if (int rc1 = conv_part(o, msg, pd)) return rc1;
+                if (!ctx.dry) LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, ev[1], 0));
+                TRY(dp.allreduce_f64(msg, 2 * Ca + 1 + 2 * Cd + 1, stream));
+                if (!ctx.dry) {
+                    LIDOG_CHECK_HIP(hipEventRecord(ev[2], (hipStream_t)stream));
+                    LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)lane, ev[2], 0));
+                }
+                if (int rc1 = bn_part(pd)) return rc1;
+                cur = lane;
+                rc = bn_part(pd2);
+                cur = stream;
+                if (rc) return rc;
+                if (!ctx.dry) {
+                    LIDOG_CHECK_HIP(hipEventRecord(ev[3], (hipStream_t)lane));
+                    join_of[nx[TO_OUT]] = ev[3];
+                }
+                ++o;
+                continue;
+            }
             if (int rc = conv_part(o, msg, pd)) return rc;
             if (int rc = conv_part(o + 1, msg + 2 * Ca + 1, pd2)) return rc;
             TRY(dp.allreduce_f64(msg, 2 * Ca + 1 + 2 * Cd + 1, stream));
@@ -555,12 +600,12 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
             hipEvent_t e_fork = nullptr, e_join = nullptr;
             if (!ctx.dry) {
                 if (!side_events) {
-                    side_events = event_pool(SIDE_EVENT0 + 32);
+                    side_events = event_pool(SIDE_EVENT0 + 64);
                     LIDOG_REQUIRE(side_events, "trunk: cannot create events");
                     side_events += SIDE_EVENT0;
                 }
-                e_fork = side_events[2 * n_side];
-                e_join = side_events[2 * n_side + 1];
+                e_fork = side_events[4 * n_side];
+                e_join = side_events[4 * n_side + 3];
                 LIDOG_CHECK_HIP(hipEventRecord(e_fork, (hipStream_t)stream));
                 LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)lane, e_fork, 0));
             }
@@ -711,9 +756,13 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     // Side branch: the downsample convolution of a layer's first block (1x1 + BatchNorm, no ReLU; its output is only the
     // residual of conv2's BatchNorm) has its backward -- BatchNorm reduce + apply, 1x1 data gradient -- on a third stream,
     // from the moment conv2's BatchNorm backward has written the residual's gradient until conv1's data gradient adds the
-    // branch's contribution to the block input's gradient.  Local BatchNorm, no gradient buckets (their events watch the
-    // launch stream and the lane only).  Same kernels, same arguments: same bits.
-    const bool side_on = g_side_backward && lane && !sync && !dp.buckets();
+    // branch's contribution to the block input's gradient.  Under SyncBatchNorm the branch's statistics message is still
+    // all-reduced ON THE LAUNCH STREAM, at the op's place in the order: the launch stream waits for the branch's reduction
+    // (long finished: conv2's data gradient was queued in between), the branch's apply pass waits for the all-reduce.
+    // Gradient buckets watch the launch stream and the lane only; that covers a side op's parameter gradients when the
+    // launch stream has waited for its reduction (SyncBatchNorm), not otherwise (local BatchNorm + buckets: in line).
+    // Same kernels, same arguments: same bits.
+    const bool side_on = g_side_backward && lane && (sync || !dp.buckets());
     hipStream_t side_st = nullptr;
     hipEvent_t *side_ev = nullptr;
     int n_side = 0;
@@ -794,7 +843,16 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
             float *dx = (float *)ga.take(n * Cout * 4);
             float *dres = has_res ? target((int)op[TO_RES]) : nullptr;
             // SyncBatchNorm: (sum dy', sum dy' xhat, rows) summed over the ranks; the apply kernel reads the global count
-            if (sync) TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
+            if (sync && side_op && !ctx.dry) {
+                hipEvent_t e1 = side_ev[4 * n_side + 2], e2 = side_ev[4 * n_side + 3];
+                LIDOG_CHECK_HIP(hipEventRecord(e1, side_st));
+                LIDOG_CHECK_HIP(hipStreamWaitEvent(main_st, e1, 0));
+                TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
+                LIDOG_CHECK_HIP(hipEventRecord(e2, main_st));
+                LIDOG_CHECK_HIP(hipStreamWaitEvent(side_st, e2, 0));
+            } else if (sync) {
+                TRY(dp.allreduce_f64(sums, 2 * Cout + 1, stream));
+            }
             TRY(lidog_bn_bwd_apply_bits(gout, pre, ymask, mbits, n, Cout, 1, mean, invstd, bnw, sums,
                                              sync ? -1.0 : (double)n, dx, dres, nullptr, nullptr,
                                              mask_from_x ? bnb : nullptr, cur));
@@ -811,7 +869,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                         LIDOG_REQUIRE(side_st && side_ev, "trunk: cannot create the side stream");
                         side_ev += SIDE_BWD_EVENT0;
                     }
-                    res_ready[rb] = side_ev[2 * n_side];
+                    res_ready[rb] = side_ev[4 * n_side];
                     LIDOG_CHECK_HIP(hipEventRecord(res_ready[rb], main_st));
                 }
             }
@@ -902,7 +960,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
                 if (int rc = gemm(ctx, m, gout, n, nullptr, Wt, nullptr, Cout, Cin, gx, nullptr, cur)) return rc;
                 if (int rc = commit(in_b, gx)) return rc;
                 if (side_op && !ctx.dry) {
-                    join_evt[in_b] = side_ev[2 * n_side + 1];
+                    join_evt[in_b] = side_ev[4 * n_side + 1];
                     LIDOG_CHECK_HIP(hipEventRecord(join_evt[in_b], side_st));
                     side_last = join_evt[in_b];
                 }
@@ -995,7 +1053,7 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
         }
         if (side_op) {
             if (!ctx.dry && !join_evt[in_b]) {   // no data gradient was asked for: still order the parameter gradients
-                side_last = side_ev[2 * n_side + 1];
+                side_last = side_ev[4 * n_side + 1];
                 LIDOG_CHECK_HIP(hipEventRecord(side_last, side_st));
             }
             ++n_side;

@@ -483,7 +483,7 @@ class _TrunkFn(torch.autograd.Function):
             arenas.fwd_owner = weakref.ref(run)
         scratch = arenas.get("scratch", int(need[1]), dev)
         if coll is not None:
-            coll.regions = (scratch,)
+            coll.regions = (scratch, arena)
         try:
             call_on(lane_raw, "lidog_trunk_forward", *args, arena.data_ptr(), arena.numel(), scratch.data_ptr(),
                     scratch.numel(), run.rec.ctypes.data, need.ctypes.data, 0, dp, _lib.stream())
