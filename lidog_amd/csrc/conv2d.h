@@ -22,6 +22,15 @@ struct IgParams {
 
 enum { IG_FWD = 0, IG_DGRAD = 1, IG_WGRAD = 2 };
 
+// up to four problems in one launch (the stride-2 parity classes of a data gradient, longest reduction first)
+struct IgClasses {
+    IgParams c[4];
+    int first[5];            // first workgroup of every class; first[n] = grid size
+    int n;
+    int row_tiles[4];        // row tiles of a pixel tile (next to each other in the grid)
+    long long list_off[4];   // sparse data gradient: the class's tile lists inside the activity buffer (int32 units)
+};
+
 #define C2_KB 32  // reduction depth of one LDS stage (FWD / DGRAD)
 
 // Wd = the data-gradient weight slabs of the four stride-2 parity classes of a 3x3 kernel W [Cout][Cin][3][3], in class

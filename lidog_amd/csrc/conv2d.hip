@@ -169,16 +169,15 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(IgParams p) {
 // WM x (4/WM) waves, each TI x TJ MFMA tiles: 128 x 128 (WM=2,TI=2,TJ=2) or 96 x 128 (WM=1,TI=3,TJ=1; the
 // data gradient of a 96-channel input would waste a quarter of a 128-row tile).
 template <int MODE, int WM, int TI, int TJ>
-__global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
+__device__ __forceinline__ void conv_s2_tile(const IgParams &p, const int bx, const int by, float *__restrict__ As,
+                                             float *__restrict__ Bs) {
     constexpr int TMR = WM * TI * 32;              // tile rows (i)
     constexpr int AV = (TMR * C2_KB / 4) / 256;    // float4 of A per thread per stage
     static_assert((4 / WM) * TJ * 32 == IG_T, "tile is 128 pixels wide");
     static_assert((TMR * C2_KB / 4) % 256 == 0, "A stage must divide over the threads");
-    __shared__ float As[C2_KB * IG_LD];
-    __shared__ float Bs[C2_KB * IG_LD];
     extern __shared__ int2 s_tab[];  // [Kd] (offset, tap)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.y * TMR, j0 = blockIdx.x * IG_T;
+    const int i0 = by * TMR, j0 = bx * IG_T;
     const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
     const int kw = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int nt = p.nky * p.nkx;
@@ -349,6 +348,26 @@ __global__ __launch_bounds__(256) void k_conv_s2(IgParams p) {
     }
 }
 
+// One launch over up to four problems (the stride-2 parity classes of a data gradient, longest reduction first) or one
+// (forward): workgroup x -> (class, pixel tile, row tile) with the row tiles of a pixel tile next to each other (the
+// second one finds the gathered pixels in L2).  Four launches of 1 744 / 1 734 / 1 734 / 1 724 equal workgroups on 512
+// slots were 3.4 rounds each, i.e. four with the last one 40 % full; one launch with the 4-tap class first lets the short
+// classes fill the long one's tail.
+// (Tried and dropped, round 5: the forward pass's pixel tiles behind the last full round of 128-row workgroups as 64-row
+// workgroups in the same launch -- 1 536 + 416 half-sized instead of 1 744 equal ones on 512 slots: 46.79 vs 46.80 ms.)
+template <int MODE, int WM, int TI, int TJ>
+__global__ __launch_bounds__(256) void k_conv_s2(IgClasses pc) {
+    __shared__ float As[C2_KB * IG_LD];
+    __shared__ float Bs[C2_KB * IG_LD];
+    const int x = blockIdx.x;
+    int cls = 0;
+    while (cls + 1 < pc.n && x >= pc.first[cls + 1]) ++cls;
+    const IgParams p = pc.c[cls];
+    const int r = x - pc.first[cls];
+    const int rt = pc.row_tiles[cls];
+    conv_s2_tile<MODE, WM, TI, TJ>(p, r / rt, r % rt, As, Bs);
+}
+
 // ------------------------------------------------------------------ weight repack for DGRAD
 // Wd[ci][co*nt + tap] = W[co][ci][ky(tap)][kx(tap)] per parity class;
 // all four parity classes (py, px) in one launch: class cls = 2 py + px owns nt = (py ? 2 : 1) (px ? 2 : 1) taps and the
@@ -494,8 +513,12 @@ extern "C" int lidog_conv2d_fwd(const float *x, const float *w, const float *bia
     if (p.Nj == 0) return 0;
     LIDOG_REQUIRE((int64_t)B * Cin * H * W < ((int64_t)1 << 31) && (int64_t)p.Kd * 8 <= 24576,
                   "conv2d_fwd: tensor too large for 32-bit offsets / reduction table");
-    dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
-    k_conv_s2<IG_FWD, 2, 2, 2><<<grid, 256, (size_t)p.Kd * sizeof(int2), st>>>(p);
+    IgClasses pc = {};
+    pc.c[0] = p;
+    pc.n = 1;
+    pc.row_tiles[0] = (int)cdiv64(p.Mi, IG_T);
+    pc.first[1] = (int)cdiv64(p.Nj, IG_T) * pc.row_tiles[0];
+    k_conv_s2<IG_FWD, 2, 2, 2><<<(unsigned)pc.first[pc.n], 256, (size_t)p.Kd * sizeof(int2), st>>>(pc);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -520,9 +543,13 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
     int Ho = out_dim(H, 3, 2, 1), Wo = out_dim(W, 3, 2, 1);
     float *slab = ws;
     lidog_launch_repack_dgrad_all(w, Cin, Cout, ws, st);
+    const bool rows96 = Cin % 128 != 0 && Cin % 96 == 0;   // 96-row tiles: no idle quarter of a 128-row tile
+    IgClasses pc = {};
+    IgParams cls_p[4];
     for (int py = 0; py < 2; ++py) {
         for (int px = 0; px < 2; ++px) {
-            IgParams p = {};
+            IgParams &p = cls_p[2 * py + px];
+            p = IgParams{};
             p.Bm = gy; p.D = gx;
             p.Bn = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Ho = Ho; p.Wo = Wo;
             p.py = py; p.px = px;
@@ -535,17 +562,23 @@ extern "C" int lidog_conv2d_dgrad(const float *gy, const float *w, int32_t B, in
             int64_t total = (int64_t)Cin * Cout * nt;
             p.A = slab;
             slab += total;
-            if (p.Nj > 0) {
-                const size_t tab = (size_t)p.Kd * sizeof(int2);
-                if (Cin % 128 != 0 && Cin % 96 == 0) {  // 96-row tiles: no idle quarter of a 128-row tile
-                    dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)(p.Mi / 96), 1);
-                    k_conv_s2<IG_DGRAD, 1, 3, 1><<<grid, 256, tab, st>>>(p);
-                } else {
-                    dim3 grid((unsigned)cdiv64(p.Nj, IG_T), (unsigned)cdiv64(p.Mi, IG_T), 1);
-                    k_conv_s2<IG_DGRAD, 2, 2, 2><<<grid, 256, tab, st>>>(p);
-                }
-            }
         }
+    }
+    // longest reduction first: (py, px) = (1, 1) has four taps, (0, 1) and (1, 0) two, (0, 0) one
+    const int rt = rows96 ? Cin / 96 : (int)cdiv64(Cin, IG_T);
+    size_t tab = 0;
+    for (int cls : {3, 1, 2, 0}) {
+        const IgParams &p = cls_p[cls];
+        if (p.Nj <= 0) continue;
+        pc.c[pc.n] = p;
+        pc.row_tiles[pc.n] = rt;
+        pc.first[pc.n + 1] = pc.first[pc.n] + (int)cdiv64(p.Nj, IG_T) * rt;
+        ++pc.n;
+        if ((size_t)p.Kd * sizeof(int2) > tab) tab = (size_t)p.Kd * sizeof(int2);
+    }
+    if (pc.n > 0) {
+        if (rows96) k_conv_s2<IG_DGRAD, 1, 3, 1><<<(unsigned)pc.first[pc.n], 256, tab, st>>>(pc);
+        else k_conv_s2<IG_DGRAD, 2, 2, 2><<<(unsigned)pc.first[pc.n], 256, tab, st>>>(pc);
     }
     LIDOG_LAUNCH_CHECK();
     return 0;

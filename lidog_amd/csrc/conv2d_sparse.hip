@@ -369,10 +369,10 @@ extern "C" int lidog_conv2d_fwd_sparse(const float *x, const float *w, const int
 // Same schedule as k_conv_s2<IG_DGRAD, 1, 3, 1> (rows i = ci, 128 class pixels per tile, k = (co, tap)), with the
 // rows of the tile = the active channels of the tile: TIA = ceil(n_act / 32) row blocks instead of Cin / 32.
 template <int TIA>
-__device__ __forceinline__ void conv_dgrad_act_body(const IgParams &p, const int *s_ch, int n_act, float *As,
-                                                    float *Bs, const int2 *s_tab) {
+__device__ __forceinline__ void conv_dgrad_act_body(const IgParams &p, const int tile, const int *s_ch, int n_act,
+                                                    float *As, float *Bs, const int2 *s_tab) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = blockIdx.x * IG_T;
+    const int j0 = tile * IG_T;
     const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
     const int kw = __builtin_amdgcn_readfirstlane(tid >> 7);
 
@@ -492,13 +492,18 @@ __device__ __forceinline__ void conv_dgrad_act_body(const IgParams &p, const int
     }
 }
 
-__global__ __launch_bounds__(256) void k_conv_dgrad_act(IgParams p, const int32_t *__restrict__ lists) {
+// the four parity classes in one launch, the four-tap class first (conv2d.hip:k_conv_s2 has the reasoning)
+__global__ __launch_bounds__(256) void k_conv_dgrad_act(IgClasses pc, const int32_t *__restrict__ act) {
     __shared__ float As[C2_KB * IG_LD];
     __shared__ float Bs[C2_KB * IG_LD];
     __shared__ int s_ch[128];
     extern __shared__ int2 s_tab[];  // [Kd] (offset, tap)
     const int tid = threadIdx.x;
-    const int32_t *lst = lists + (size_t)blockIdx.x * (p.Cin + 1);
+    int cls = 0;
+    while (cls + 1 < pc.n && (int)blockIdx.x >= pc.first[cls + 1]) ++cls;
+    const IgParams p = pc.c[cls];
+    const int tile = (int)blockIdx.x - pc.first[cls];
+    const int32_t *lst = act + pc.list_off[cls] + (size_t)tile * (p.Cin + 1);
     const int n_act = lst[0];
     if (n_act == 0) return;  // workgroup-uniform: nothing of this tile is needed
     if (tid < n_act) s_ch[tid] = lst[1 + tid];
@@ -509,10 +514,10 @@ __global__ __launch_bounds__(256) void k_conv_dgrad_act(IgParams p, const int32_
         s_tab[kk] = make_int2(co * HoWo - ty * p.Wo - tx, ty * 2 + tx);
     }
     __syncthreads();
-    if (n_act <= 32) conv_dgrad_act_body<1>(p, s_ch, n_act, As, Bs, s_tab);
-    else if (n_act <= 64) conv_dgrad_act_body<2>(p, s_ch, n_act, As, Bs, s_tab);
-    else if (n_act <= 96) conv_dgrad_act_body<3>(p, s_ch, n_act, As, Bs, s_tab);
-    else conv_dgrad_act_body<4>(p, s_ch, n_act, As, Bs, s_tab);
+    if (n_act <= 32) conv_dgrad_act_body<1>(p, tile, s_ch, n_act, As, Bs, s_tab);
+    else if (n_act <= 64) conv_dgrad_act_body<2>(p, tile, s_ch, n_act, As, Bs, s_tab);
+    else if (n_act <= 96) conv_dgrad_act_body<3>(p, tile, s_ch, n_act, As, Bs, s_tab);
+    else conv_dgrad_act_body<4>(p, tile, s_ch, n_act, As, Bs, s_tab);
 }
 
 extern "C" int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const int32_t *act, int32_t B, int32_t Cin,
@@ -527,9 +532,11 @@ extern "C" int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const 
     ActLayout L = act_layout(B, Cin, H, W);
     float *slab = ws;
     lidog_launch_repack_dgrad_all(w, Cin, Cout, ws, st);   // conv2d.hip: the four classes' weight slabs, one launch
+    IgParams cls_p[4];
     for (int cls = 0; cls < 4; ++cls) {
         int py = cls >> 1, px = cls & 1;
-        IgParams p = {};
+        IgParams &p = cls_p[cls];
+        p = IgParams{};
         p.Bm = gy; p.D = gx;
         p.Bn = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.Ho = Ho; p.Wo = Wo;
         p.py = py; p.px = px;
@@ -541,10 +548,19 @@ extern "C" int lidog_conv2d_dgrad_sparse(const float *gy, const float *w, const 
         int64_t total = (int64_t)Cin * Cout * nt;
         p.A = slab;
         slab += total;
-        if (p.Nj > 0)
-            k_conv_dgrad_act<<<(unsigned)L.dgrad_tiles[cls], 256, (size_t)p.Kd * sizeof(int2), st>>>(
-                p, act + L.dgrad_off[cls]);
     }
+    IgClasses pc = {};
+    size_t tab = 0;
+    for (int cls : {3, 1, 2, 0}) {
+        const IgParams &p = cls_p[cls];
+        if (p.Nj <= 0 || L.dgrad_tiles[cls] <= 0) continue;
+        pc.c[pc.n] = p;
+        pc.list_off[pc.n] = (long long)L.dgrad_off[cls];
+        pc.first[pc.n + 1] = pc.first[pc.n] + (int)L.dgrad_tiles[cls];
+        ++pc.n;
+        if ((size_t)p.Kd * sizeof(int2) > tab) tab = (size_t)p.Kd * sizeof(int2);
+    }
+    if (pc.n > 0) k_conv_dgrad_act<<<(unsigned)pc.first[pc.n], 256, tab, st>>>(pc, act);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
