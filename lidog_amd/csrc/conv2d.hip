@@ -610,7 +610,10 @@ extern "C" int lidog_conv2d_wgrad(const float *x, const float *gy, int32_t B, in
     p.Mi = Cout; p.Nj = Cin * 9; p.Kd = B * p.Ho * p.Wo;
     int64_t slab = (int64_t)p.Mi * p.Nj;
     int tiles = (int)(cdiv64(p.Nj, IG_T) * cdiv64(p.Mi, IG_T));
-    int splits = (int)cdiv64(1024, tiles);
+    // two full rounds of the chip's slots (211 registers: two workgroups per CU, 512 slots on 256 CUs), never a few
+    // workgroups more: 36 tiles x 29 splits = 1 044 workgroups ran a third round for the last 20 (round 5)
+    int splits = 1024 / tiles;
+    if (splits < 1) splits = 1;
     LIDOG_REQUIRE(Cout % 8 == 0, "conv2d_wgrad: Cout must be a multiple of 8");
     LIDOG_REQUIRE((int64_t)Cin * H * W < ((int64_t)1 << 27) && (int64_t)B * Cin * H * W < ((int64_t)1 << 31) &&
                       (int64_t)B * Cout * p.Ho * p.Wo < ((int64_t)1 << 31),
