@@ -182,6 +182,10 @@ int lidog_sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, con
 
 /* slots of Cin*Cout floats that `partial` must hold for lidog_sconv_wgrad with n_items work items */
 int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_items);
+/* workgroups of lidog_sconv_wgrad (fold != 0: lidog_sconv_wgrad_in_bn) for Cin x Cout that are resident on the chip at a
+ * time (occupancy x CUs): the caller cuts the rule book so that a launch is a whole number of rounds (me._wgrad_items;
+ * ME's own weight gradient, MinkowskiConvolution backward, has no such knob).  0: not a matrix-core shape. */
+int32_t lidog_sconv_wgrad_slots(int32_t Cin, int32_t Cout, int32_t fold);
 
 /* Arithmetic core of lidog_sconv_gemm / lidog_sconv_wgrad: 1 = exact-f32 MFMA (default), 0 = vector FMA.
  * Both produce bit-identical results (an f32 MFMA is a k-ordered fmaf chain); kept selectable for A/B. */

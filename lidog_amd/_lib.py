@@ -51,6 +51,7 @@ SIGNATURES = {
                                    _p, _p, _p, _p, _i32, _p],
     "lidog_sconv_wgrad_in_bn": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
     "lidog_sconv_wgrad_slabs": [_i32, _i32, _i32],
+    "lidog_sconv_wgrad_slots": [_i32, _i32, _i32],
     "lidog_set_sparse_core": [_i32],
     "lidog_get_sparse_core": [],
     "lidog_transpose_kernel": [_p, _i32, _i32, _i32, _p, _p],

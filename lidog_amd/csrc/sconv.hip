@@ -1228,6 +1228,18 @@ extern "C" int lidog_sconv_wgrad_slabs(int32_t Cin, int32_t Cout, int32_t n_item
     return n_items;
 }
 
+// Slots of one weight-gradient launch: workgroups of the Cin x Cout kernel that are resident on the chip at a time
+// (per-CU occupancy of the kernel x CUs); fold: the lidog_sconv_wgrad_in_bn form.  The caller (lidog_amd/me.py) cuts the
+// rule book into work items so that a launch is a whole number of rounds of these slots.  0: not a matrix-core shape.
+extern "C" int32_t lidog_sconv_wgrad_slots(int32_t Cin, int32_t Cout, int32_t fold) {
+    if (!(g_sparse_core == 1 && pick_tile(Cin) && pick_tile(Cout))) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    int per = lidog_wgrad_mfma_wg_per_cu(Cin, Cout, fold);
+    return per > 0 ? per * cus : 0;
+}
+
 static int sconv_wgrad(const float *A, const int32_t *pair_a, const float *G, const int32_t *pair_g,
                        const int32_t *items, int32_t n_items, const int32_t *item_off, int32_t K, int32_t Cin,
                        int32_t Cout, float *partial, float *gW, InBn in_bn, void *stream) {

@@ -29,3 +29,4 @@ int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, c
                             const int32_t *items, int n_items, int Cin, int Cout, float *partial, InBn in_bn,
                             hipStream_t st);
 int lidog_wgrad_mfma_slabs(int Cin, int Cout, int n_items);
+int lidog_wgrad_mfma_wg_per_cu(int Cin, int Cout, int fold);

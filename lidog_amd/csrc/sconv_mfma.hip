@@ -523,6 +523,40 @@ static void launch_wg(dim3 grid, hipStream_t st, const float *A, const int32_t *
                                                                               partial, in_bn);
 }
 
+template <int MT, int NT, int NW, int NGRP>
+static int occ_wg(bool fold) {
+    int n = 0;
+    hipError_t e = fold ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sconv_wgrad_mfma<MT, NT, NW, NGRP, true>, 64 * NW, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sconv_wgrad_mfma<MT, NT, NW, NGRP, false>, 64 * NW, 0);
+    return e == hipSuccess ? n : -1;
+}
+
+// workgroups of the weight-gradient kernel for Cin x Cout that fit one CU at a time (the caller sizes its work items so
+// that a launch is a whole number of rounds of the chip's slots); -1 on error
+int lidog_wgrad_mfma_wg_per_cu(int Cin, int Cout, int fold) {
+    int mt = tile32(Cin), nt = tile32(Cout);
+#define WG(MT_, NT_, NW_, NG_) return occ_wg<MT_, NT_, NW_, NG_>(fold != 0)
+    switch (mt * 10 + nt) {
+        case 11: WG(1, 1, 4, 4);
+        case 12: WG(1, 2, 4, 2);
+        case 21: WG(2, 1, 4, 2);
+        case 13: WG(1, 3, 3, 1);
+        case 31: WG(3, 1, 3, 1);
+        case 14: WG(1, 4, 4, 1);
+        case 41: WG(4, 1, 4, 1);
+        case 22: WG(2, 2, 4, 1);
+        case 23: WG(2, 3, 3, 1);
+        case 32: WG(3, 2, 3, 1);
+        case 24: WG(2, 4, 4, 1);
+        case 42: WG(4, 2, 4, 1);
+        case 33: WG(3, 3, 3, 1);
+        case 34: WG(3, 4, 4, 1);
+        case 43: WG(4, 3, 4, 1);
+        default: WG(4, 4, 4, 1);
+    }
+#undef WG
+}
+
 int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, const int32_t *pg,
                             const int32_t *items, int n_items, int Cin, int Cout, float *partial, InBn in_bn,
                             hipStream_t st) {

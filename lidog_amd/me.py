@@ -408,7 +408,7 @@ class CoordinateManager:
                 koh = self.kmaps[key].k_off_host
             seen = set()
             for cin, cout in shapes[key]:
-                chunk = _wgrad_chunk(int(koh[-1]), cin, cout)
+                chunk = _wgrad_chunk(koh, cin, cout)
                 if chunk in seen:
                     continue
                 seen.add(chunk)
@@ -756,8 +756,27 @@ _WGRAD_TARGET_BLOCKS = int(os.environ.get("LIDOG_WGRAD_BLOCKS", "2048"))
 _WGRAD_WIDE_BLOCKS = int(os.environ.get("LIDOG_WGRAD_WIDE_BLOCKS", str(_WGRAD_TARGET_BLOCKS // 2)))
 
 
-def _wgrad_chunk(P, Cin, Cout):
-    """pairs per weight-gradient work item for a rule book of P pairs"""
+# LIDOG_WGRAD_FIT: 1 = the work items of a launch fill a whole number of rounds of the kernel's slots (see _wgrad_chunk;
+# rounds = nearest to the measured optimum, 2 = rounded up); 0 = items ~ the optimum + one partial item per offset, i.e.
+# usually a dozen workgroups MORE than a whole number of rounds.  Default (-1): 1 when the weight gradients run in line on
+# the launch stream, 0 when they run on the second stream.  Measured (same box, alternating, round 5): in line the fitted
+# launches save 0.7 ms of kernel time per step (51.16 -> 50.44 ms); on the second stream they LOSE 0.25 ms (47.48 ->
+# 47.75): the loose last round of a lane kernel is when the launch stream's kernels get the chip to themselves.
+_WGRAD_FIT = int(os.environ.get("LIDOG_WGRAD_FIT", "-1"))
+_wgrad_slots_cache = {}
+
+
+def _wgrad_slots(Cin, Cout):
+    key = (Cin, Cout)
+    if key not in _wgrad_slots_cache:
+        _wgrad_slots_cache[key] = int(_lib.load().lidog_sconv_wgrad_slots(Cin, Cout, 0))
+    return _wgrad_slots_cache[key]
+
+
+def _wgrad_chunk(k_off_host, Cin, Cout):
+    """pairs per weight-gradient work item for a rule book with offsets k_off_host [K + 1]"""
+    P = int(k_off_host[-1]) - int(k_off_host[0])
+
     def tile(c):
         for t in (128, 96, 64, 32):
             if c % t == 0:
@@ -770,8 +789,20 @@ def _wgrad_chunk(P, Cin, Cout):
     if Cin * Cout >= 256 * 256:
         blocks = _WGRAD_WIDE_BLOCKS
     target = max(1, blocks // tiles)
-    chunk = max(128, -(-P // target))
     max_items = max(1, (192 << 20) // (4 * Cin * Cout))             # at most ~192 MB of partial slots
+    fit = _WGRAD_FIT if _WGRAD_FIT >= 0 else (0 if _WgradLane.enabled else 1)
+    slots = _wgrad_slots(Cin, Cout) if fit else 0
+    if slots and blocks > slots:
+        # Every offset ends in a partial item, so P / chunk items are really ~K / 2 more: 2 048 wanted on 512 slots became
+        # ~2 060, a fifth round for a dozen workgroups.  Cut so that the launch is at most `rounds` whole rounds.
+        rounds = -(-blocks // slots) if fit == 2 else max(1, int(blocks / slots + 0.5))
+        budget = min(max(1, rounds * slots // tiles), max_items)
+        cnt = np.diff(np.asarray(k_off_host, dtype=np.int64))
+        chunk = max(128, (-(-P // budget) + 31) // 32 * 32)
+        while int(np.sum((cnt + chunk - 1) // chunk)) > budget:
+            chunk += 32
+        return chunk
+    chunk = max(128, -(-P // target))
     chunk = max(chunk, -(-P // max_items))
     return (chunk + 31) // 32 * 32
 
@@ -805,7 +836,7 @@ def _wgrad_items(m, Cin, Cout):
     that: equal splits per offset would leave most workgroups idle behind the centre ones).
     Returns (items int32 [3, n] on the device, n, item_off int32 [K+1] on the device); cached on the map
     (CoordinateManager.prefetch fills the cache ahead of the backward pass)."""
-    chunk = _wgrad_chunk(m.P, Cin, Cout)
+    chunk = _wgrad_chunk(m.k_off_host, Cin, Cout)
     cache = m.__dict__.setdefault("_wgrad_items", {})
     if chunk not in cache:
         items, total, item_off = _wgrad_items_host(m.k_off_host, chunk)

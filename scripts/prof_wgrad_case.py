@@ -58,7 +58,7 @@ if HYB:   # experiment (round 5): the dense offsets (>= DENSE pairs per row) cut
     dense = [k for k in range(m.K) if cnt[k] >= DENSE * m.n_out]
     nb = (m.n_out + HYB - 1) // HYB
     edges = np.arange(nb + 1, dtype=np.int64) * HYB
-    chunk = ME._wgrad_chunk(m.P, Cin, Cout)
+    chunk = ME._wgrad_chunk(m.k_off_host, Cin, Cout)
     rows, tag = [], []          # (k, p0, p1), tag = block id for dense items, -1 for sparse ones
     for k in range(m.K):
         if k in dense:
