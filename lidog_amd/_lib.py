@@ -139,7 +139,7 @@ _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "
 
 # lidog_abi_version() of the library these signatures were written against: a stale .so (or a header an external caller
 # compiled against long ago) would take mis-sized arguments without any diagnostic
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
