@@ -793,8 +793,8 @@ def _wgrad_chunk(k_off_host, Cin, Cout):
     fit = _WGRAD_FIT if _WGRAD_FIT >= 0 else (0 if _WgradLane.enabled else 1)
     slots = _wgrad_slots(Cin, Cout) if fit else 0
     if slots and blocks > slots:
-        # Every offset ends in a partial item, so P / chunk items are really ~K / 2 more: 2 048 wanted on 512 slots became
-        # ~2 060, a fifth round for a dozen workgroups.  Cut so that the launch is at most `rounds` whole rounds.
+        # Every offset ends in a partial item (P / chunk items are really ~K / 2 more) and the swept optimum is not a
+        # multiple of the slots: 2 048 wanted on 768 slots = 2.7 rounds.  Cut so that the launch is `rounds` whole rounds.
         rounds = -(-blocks // slots) if fit == 2 else max(1, int(blocks / slots + 0.5))
         budget = min(max(1, rounds * slots // tiles), max_items)
         cnt = np.diff(np.asarray(k_off_host, dtype=np.int64))

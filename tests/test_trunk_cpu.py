@@ -212,3 +212,32 @@ def test_program_follows_structural_changes_of_the_model():
     model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
     p2 = trunk.program_of(model)
     assert p2 is not p1 and all(type(b) is ME.MinkowskiSyncBatchNorm for b in p2.bns)
+
+
+def test_weight_gradient_work_items_fill_whole_rounds_when_asked(monkeypatch):
+    """me._wgrad_chunk: with LIDOG_WGRAD_FIT the items of a launch (one partial item per offset included) fit a whole
+    number of rounds of the kernel's resident workgroups, tightly; without it the round-4 rule (pairs / optimum, which
+    overshoots by about half an item per offset).  Slots come from the GPU library: stubbed here."""
+    import lidog_amd.me as ME
+    rng = np.random.default_rng(3)
+    # a 3^3 rule book like the bench's stride-1 map: the centre offset owns one pair per voxel, the others 5-40 %
+    n = 352_000
+    cnt = (n * np.concatenate([rng.uniform(0.05, 0.4, 13), [1.0], rng.uniform(0.05, 0.4, 13)])).astype(np.int64)
+    k_off = np.concatenate([[0], np.cumsum(cnt)])
+    items = lambda chunk: int(np.sum((cnt + chunk - 1) // chunk))   # noqa: E731
+    monkeypatch.setattr(ME, "_wgrad_slots", lambda cin, cout: {96: 512, 128: 768, 256: 768}[cin])
+    monkeypatch.setattr(ME, "_WGRAD_FIT", 0)
+    old = ME._wgrad_chunk(k_off, 128, 128)
+    assert old % 32 == 0 and 2048 - 40 < items(old) < 2048 + 40   # ~2 048 +- partial items: 2.67 rounds of 768 slots
+    monkeypatch.setattr(ME, "_WGRAD_FIT", 1)
+    for (cin, cout, tiles, slots) in ((96, 96, 1, 512), (128, 128, 1, 768), (256, 256, 4, 768)):
+        chunk = ME._wgrad_chunk(k_off, cin, cout)
+        wgs = items(chunk) * tiles
+        rounds = -(-wgs // slots)
+        assert chunk % 32 == 0 and wgs <= rounds * slots
+        assert items(chunk - 32) * tiles > rounds * slots or chunk == 128, "not the smallest chunk that fits"
+    monkeypatch.setattr(ME, "_WGRAD_FIT", -1)           # default: by stream mode
+    monkeypatch.setattr(ME._WgradLane, "enabled", True)
+    assert ME._wgrad_chunk(k_off, 128, 128) == old
+    monkeypatch.setattr(ME._WgradLane, "enabled", False)
+    assert items(ME._wgrad_chunk(k_off, 128, 128)) <= 3 * 768      # 2 048 / 768 = 2.67 -> three whole rounds
