@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak = vector fp32 peak (MI355X_MICROARCH.md, Matrix cores)
 # scripts/profile_round.sh <tag> writes profiles/<tag>_pmc_traffic_sconv_gemm_mfma.json (FETCH_SIZE / WRITE_SIZE passes)
-PMC_TRAFFIC_TAG = "r05_e"
+PMC_TRAFFIC_TAG = "r05_f"
 PMC_TRAFFIC_FILE = f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_gemm_mfma.json"
 
 
