@@ -33,6 +33,17 @@ FP32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak = vector fp32 peak (MI355X_MICR
 # scripts/profile_round.sh <tag> writes profiles/<tag>_pmc_traffic_sconv_gemm_mfma.json (FETCH_SIZE / WRITE_SIZE passes)
 PMC_TRAFFIC_TAG = "r05_f"
 PMC_TRAFFIC_FILE = f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_gemm_mfma.json"
+# An N > 1 run that prints nothing for this long is taken to be hung (a collective that never completes): the driver
+# allows the whole command 600 s, so the silence limit plus one safe-mode re-run must fit well inside that.  Every rank
+# reports its progress on stderr (beat() below) at least once per block of timed steps.
+WATCHDOG_DEFAULT_S = 150.0
+
+
+def beat(msg):
+    """one progress line on stderr -- what the silence watchdogs above this process (supervise_rank, launch_ranks)
+    listen for; never on stdout, which carries rank 0's JSON line only"""
+    sys.stderr.write(f"bench.py[rank {os.environ.get('RANK', '0')}]: {msg}\n")
+    sys.stderr.flush()
 
 
 def parse():
@@ -180,8 +191,19 @@ def cpu_whole_host(config, threads_per_worker, single):
     forced = os.environ.get("LIDOG_CPU_BASELINE_WORKERS")
     workers = int(forced) if forced else max(1, ncpu // threads_per_worker)
     workers = min(workers, 32)
+    # a worker holds the oracle's activations of one 120 k-point scan plus torch's autograd graph: about 10 GB at the peak
+    # of its backward pass; never start more than the memory that is free right now can hold (a host OOM kill would take
+    # the parent, and with it the headline line, along)
+    mem_cap = None
+    try:
+        avail_kb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1])
+        mem_cap = max(1, int(avail_kb * 1024 * 0.6 // (10 << 30)))
+    except (OSError, IndexError, ValueError):
+        pass
+    if mem_cap is not None and not forced:
+        workers = min(workers, mem_cap)
     out = {"usable_cpus": ncpu, "usable_cpus_source": how, "host_cpu_count": os.cpu_count(),
-           "threads_per_worker": threads_per_worker, "workers": workers, "unit": "scans/s"}
+           "threads_per_worker": threads_per_worker, "workers": workers, "workers_memory_cap": mem_cap, "unit": "scans/s"}
     if workers == 1:
         out.update(value=single, cores=threads_per_worker, same_as_single_process=True,
                    sample="one worker's worth of usable cpus: the single-process figure above is the whole-host figure")
@@ -192,14 +214,21 @@ def cpu_whole_host(config, threads_per_worker, single):
                                str(threads_per_worker), str(100 + 10 * w), "2"],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for w in range(workers)]
     rates, spans = [], []
+    # ONE deadline for the whole leg (the workers run at the same time: a worker's three steps take about 15 s alone, a
+    # few times that next to the others); whoever has not answered by then is killed, reaped and not counted
+    deadline = time.time() + float(os.environ.get("LIDOG_CPU_BASELINE_DEADLINE_S", "180"))
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
             d = json.loads([l for l in o.splitlines() if l.startswith("{")][-1])
             rates.append(d["steps"] / d["seconds"])
             spans.append((d["t0"], d["t1"]))
-        except Exception:       # a worker that died (memory) is simply not counted, and said so
+        except Exception:       # a worker that died (memory) or overran is simply not counted, and said so
             p.kill()
+            try:
+                p.communicate(timeout=10)
+            except Exception:
+                pass
     overlap = (min(t1 for _, t1 in spans) - max(t0 for t0, _ in spans)) / max(t1 - t0 for t0, t1 in spans) if spans else 0.0
     out.update(value=sum(rates), cores=threads_per_worker * len(rates), workers_finished=len(rates),
                per_worker_scans_per_s=[round(r, 4) for r in rates], timed_windows_overlap=round(overlap, 3),
@@ -329,9 +358,11 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher's environment: start the N ranks as fresh children -- the driver's own
     line, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
     bench.py ...` -- BEFORE this process touches the GPU (a process that has initialised HIP must not be replaced or
-    forked), relay what they print (rank 0's JSON line) and exit with their code.  A watchdog ends a run that prints
-    nothing for LIDOG_BENCH_WATCHDOG_S seconds (default 1500): the children's process group is killed and the parent
-    exits non-zero, so a hung collective can never hang the caller."""
+    forked), relay what they print (rank 0's JSON line) and exit with their code.  Every rank supervises itself
+    (supervise_rank: silence for LIDOG_BENCH_WATCHDOG_S seconds, default 150, ends the rank's worker and starts the
+    safe-mode fallback); this process is the outer guard: when NOTHING arrives for that long plus a minute -- not even
+    the supervisors' own messages -- the children's process group is killed and the parent exits non-zero, so a hung
+    collective can never hang the caller."""
     import signal
     import socket
     import subprocess
@@ -342,7 +373,8 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.environ.get("LIDOG_BENCH_RANK_SCRIPT", os.path.abspath(__file__))] + sys.argv[1:]   # (script override: tests)
-    limit = float(os.environ.get("LIDOG_BENCH_WATCHDOG_S", "1500"))
+    limit = float(os.environ.get("LIDOG_BENCH_WATCHDOG_S", str(WATCHDOG_DEFAULT_S)))
+    limit += min(60.0, limit)        # the ranks' own supervisors act first
     env = dict(os.environ, LIDOG_BENCH_LAUNCHED_BY_PARENT="1")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, start_new_session=True, text=True)
     last = [time.time()]
@@ -378,6 +410,96 @@ def launch_ranks(args):
     sys.exit(rc if rc >= 0 else 128 - rc)
 
 
+def supervise_rank():
+    """What a rank of an N > 1 run IS, whoever launched it (bench.py's own launcher above or the driver's
+    `python -m torch.distributed.run ... bench.py --gpus N` line): a supervisor that never touches the GPU and does the
+    rank's work in a CHILD (the same command line with LIDOG_BENCH_WORKER=1; its stdout is this process's stdout, its
+    stderr is relayed line by line).  Three RCCL communicators, a bucket stream and the executor's side streams have
+    never met a second GPU on the build's one-GPU boxes, so the first N > 1 step may hang; then
+
+    * a worker that reports nothing (beat()) for LIDOG_BENCH_WATCHDOG_S seconds (default 150) is killed with its
+      process group -- the supervisor holds no GPU state, so nothing of the hung run survives in it --,
+    * a FRESH worker runs the same measurement in safe mode (LIDOG_DP_SAFE=1, lidog_amd/__init__.py: one communicator,
+      gradient buckets on the compute stream after backward, no peer mailboxes, no side streams) on a rendezvous port
+      derived from the first one, without the launcher's TORCHELASTIC_* variables (rank 0's worker serves the store
+      itself), and rank 0 prints that line with "mode": "safe-fallback",
+    * and the supervisor exits NON-ZERO either way (124: the fallback printed its line; 125: it failed too), so a
+      degraded figure can never pass for the real one.
+
+    A worker that EXITS (any code) is not a hang: the supervisor leaves with its code and the launcher ends the other
+    ranks.  SIGTERM / SIGINT (the launcher tearing the job down) end the worker's process group first.
+    LIDOG_BENCH_FALLBACK=0 skips the second run; LIDOG_BENCH_WORKER_SCRIPT replaces the worker (tests)."""
+    import signal
+    import subprocess
+    import threading
+    limit = float(os.environ.get("LIDOG_BENCH_WATCHDOG_S", str(WATCHDOG_DEFAULT_S)))
+    script = os.environ.get("LIDOG_BENCH_WORKER_SCRIPT", os.path.abspath(__file__))
+    current = [None]
+
+    def stop_child():
+        p = current[0]
+        if p is None or p.poll() is not None:
+            return
+        for sig, wait in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                return
+            try:
+                p.wait(timeout=wait)
+                return
+            except subprocess.TimeoutExpired:
+                continue
+
+    def on_signal(signum, frame):
+        stop_child()
+        os._exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+
+    def run_worker(extra, fallback):
+        env = dict(os.environ, LIDOG_BENCH_WORKER="1", **extra)
+        if fallback:
+            env = {k: v for k, v in env.items() if not k.startswith("TORCHELASTIC_") and k != "LIDOG_BENCH_FAULT"}
+        p = subprocess.Popen([sys.executable, script] + sys.argv[1:], stderr=subprocess.PIPE, env=env,
+                             start_new_session=True, text=True)
+        current[0] = p
+        last = [time.time()]
+
+        def pump():
+            for line in p.stderr:
+                last[0] = time.time()
+                sys.stderr.write(line)
+                sys.stderr.flush()
+
+        t = threading.Thread(target=pump, daemon=True)
+        t.start()
+        while True:
+            rc = p.poll()
+            if rc is not None:
+                t.join(timeout=5)
+                return rc, False
+            if time.time() - last[0] > limit:
+                stop_child()
+                return None, True
+            time.sleep(0.25)
+
+    rc, silent = run_worker({}, False)
+    if not silent:
+        sys.exit(rc if rc >= 0 else 128 - rc)
+    beat(f"worker reported nothing for {limit:.0f} s and was killed")
+    if os.environ.get("LIDOG_BENCH_FALLBACK", "1") == "0":
+        sys.exit(124)
+    port = 20000 + (int(os.environ.get("MASTER_PORT", "29500")) + 7919) % 40000      # the same on every rank
+    beat(f"starting the safe-mode fallback (LIDOG_DP_SAFE=1, rendezvous port {port})")
+    rc, silent = run_worker(dict(LIDOG_DP_SAFE="1", LIDOG_BENCH_MODE="safe-fallback", MASTER_ADDR="127.0.0.1",
+                                 MASTER_PORT=str(port), LIDOG_BENCH_PROBE="0"), True)
+    if silent:
+        beat("the safe-mode fallback went silent too and was killed")
+    sys.exit(124 if (rc == 0 and not silent) else 125)
+
+
 PROBE_SCRIPT = os.path.join(REPO, "scripts", "micro_peer_allreduce.py")
 
 
@@ -400,6 +522,7 @@ def probe_phase(prefix, env):
     if os.environ.get("LIDOG_BENCH_PROBE", "1") == "0":
         return None
     limit = min(120.0, float(os.environ.get("LIDOG_BENCH_PROBE_WATCHDOG_S", "120")))
+    beat(f"peer probe phase (at most {limit:.0f} s, result ignored)")
     script = os.environ.get("LIDOG_BENCH_PROBE_SCRIPT", PROBE_SCRIPT)       # (override: tests)
     env = {k: v for k, v in env.items() if k not in ("LIDOG_PEER_ALLREDUCE", "LIDOG_PEER_FAULT")}
     try:
@@ -439,7 +562,8 @@ def probe_phase(prefix, env):
 # `config.env`, so that a line can never silently describe another workload or another build of the step.
 _LAUNCH_ONLY_ENV = ("LIDOG_BENCH_LAUNCHED_BY_PARENT", "LIDOG_BENCH_WATCHDOG_S", "LIDOG_BENCH_RANK_SCRIPT",
                     "LIDOG_BENCH_PROBE", "LIDOG_BENCH_PROBE_WATCHDOG_S", "LIDOG_CPU_BASELINE_THREADS",
-                    "LIDOG_CPU_BASELINE_WORKERS")
+                    "LIDOG_CPU_BASELINE_WORKERS", "LIDOG_CPU_BASELINE_DEADLINE_S", "LIDOG_BENCH_WORKER",
+                    "LIDOG_BENCH_WORKER_SCRIPT", "LIDOG_BENCH_FALLBACK", "LIDOG_BENCH_MODE", "LIDOG_BENCH_PROBE_SCRIPT")
 
 
 def experiment_env():
@@ -461,6 +585,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        # checked before any collective or GPU work: every rank sees the same mismatch and leaves with the same message
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; run "
+                 f"`python bench.py --gpus {args.gpus}` (it starts its ranks itself) or launch {args.gpus} ranks")
+    if world > 1 and os.environ.get("LIDOG_BENCH_WORKER") != "1":
+        return supervise_rank()
+    beat("worker up" + (f" (mode {os.environ['LIDOG_BENCH_MODE']})" if "LIDOG_BENCH_MODE" in os.environ else ""))
     # stdout carries ONE line, rank 0's JSON.  RCCL prints a version banner to file descriptor 1 when its first
     # communicator comes up, and other native libraries may do the same: in a distributed run descriptor 1 is pointed at
     # stderr for the life of the process and the result line is written to the saved descriptor (emit() below).
@@ -475,10 +606,6 @@ def main():
             print(line, flush=True)
         else:
             os.write(result_fd, (line + "\n").encode())
-    if world != args.gpus:
-        # checked before any collective or GPU work: every rank sees the same mismatch and leaves with the same message
-        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; run "
-                 f"`python bench.py --gpus {args.gpus}` (it starts its ranks itself) or launch {args.gpus} ranks")
     # test hooks only: LIDOG_BENCH_ONE_GPU=1 runs every rank on cuda:0 over gloo so the multi-rank control flow
     # (SyncBN conversion, gradient buckets, barriers, max-over-ranks) can be exercised on a 1-GPU box
     one_gpu = os.environ.get("LIDOG_BENCH_ONE_GPU") == "1"
@@ -501,6 +628,7 @@ def main():
                     sk.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        beat(f"process group up ({dist.get_backend()}, {world} ranks)")
 
     import lidog_amd
     import lidog_amd.me as ME
@@ -510,6 +638,16 @@ def main():
     if single_dp:
         from lidog_amd.trainer import GradientBuckets
         ME.MinkowskiSyncBatchNorm.single_rank = GradientBuckets.single_rank = True
+    fault = os.environ.get("LIDOG_BENCH_FAULT", "").split(":")
+    if fault[0] == "bucket_hang" and int(fault[1]) == rank:
+        # test hook of the watchdog (tests/test_gpu_dist.py): this rank never issues its first gradient bucket, so every
+        # other rank waits in that all-reduce for ever -- what a collective that hangs between two GPUs looks like
+        from lidog_amd.optim import GradientBuckets as _GB
+
+        def _never(self, b):
+            beat("injected fault: hanging in front of a gradient bucket (LIDOG_BENCH_FAULT)")
+            time.sleep(1e6)
+        _GB._reduce = _never
     timer = GemmTimer()
     head_timer = None
     if not args.no_kernel_timing:
@@ -528,6 +666,7 @@ def main():
     batches = [synth.make_batch(range(base + i * args.batch, base + (i + 1) * args.batch), args.config, "cuda")
                for i in range(2)]
     n_vox = sum(b["coords_int"].shape[0] for b in batches) / (2 * args.batch)
+    beat("model, optimiser and batches ready")
     # the workload is BASELINE.md's: scan seed 0 must have SURVEY.md 8(d)'s per-stride voxel counts
     seed0_counts = None
     if args.config in synth.BASELINE_COUNTS:
@@ -566,7 +705,11 @@ def main():
 
     for i in range(args.warmup):
         out = run(i)
+        if i == 0:
+            sync()      # the first step (every collective's first use) has completed on every rank
+            beat("first step done")
     sync()
+    beat(f"{args.warmup} warm-up steps done")
     # The timed region is EXACTLY --steps steps between two (barrier + synchronize) brackets, max over ranks.  A block
     # of 20 steps lasts one second, inside a process whose life is dominated by start-up and the CPU-baseline leg; so
     # the block is repeated until about --min-seconds of step time have been measured (same count on every rank: it
@@ -598,6 +741,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_block = float(t.item())
         blocks.append(dt_block)
+        beat(f"block {len(blocks)}: {1e3 * dt_block / args.steps:.2f} ms per step")
         if len(blocks) == 1:
             n_blocks = max(1, min(args.max_blocks, int(-(-args.min_seconds // dt_block))))
     ordered = sorted(blocks)
@@ -692,7 +836,11 @@ def main():
                           "global_batch": world * args.batch,
                           "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else ""),
                           "env": experiment_env()},
-               "blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in blocks], "loss": loss}
+               "blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in blocks], "loss": loss,
+               # "safe-fallback": the line of supervise_rank's second run after the first one went silent
+               "mode": os.environ.get("LIDOG_BENCH_MODE", "normal")}
+        if os.environ.get("LIDOG_DP_SAFE") == "1":
+            res["config"]["dp_safe"] = "LIDOG_DP_SAFE=1: torch.distributed collectives only, buckets after backward, no side streams"
         if world > 1 or single_dp:
             from lidog_amd.comm import transport
             from lidog_amd import _lib as _L
@@ -795,6 +943,7 @@ def main():
             if wh.get("value"):
                 res["gpu_over_cpu_whole_host"] = value / wh["value"]
         emit(json.dumps(res))
+    beat("result line out" if rank == 0 else "timed region done")
     probe_port = None
     if world > 1 and os.environ.get("LIDOG_BENCH_LAUNCHED_BY_PARENT") != "1" and not peer_error:
         # ranks started by somebody else's launcher (the driver's torch.distributed.run line): there is no parent of ours

@@ -44,6 +44,20 @@ def _hardware_queues():
 
 _hardware_queues()
 
+
+def _safe_mode():
+    """LIDOG_DP_SAFE=1: the most conservative data-parallel schedule this package has -- what bench.py falls back to
+    after an N > 1 run went silent (train_lidog.py:227-231's SyncBatchNorm + DDP, nothing else).  One communicator only
+    (torch.distributed's own, for the statistics messages AND the gradient buckets), the buckets reduced on the compute
+    stream after backward has ended (optim.GradientBuckets.deferred), no peer mailboxes, no downsample branches on
+    side streams.  Set before the library reads its switches; explicit settings of the four switches are overridden."""
+    if _os.environ.get("LIDOG_DP_SAFE") == "1":
+        _os.environ.update(LIDOG_DP_TRANSPORT="torch", LIDOG_DP_BUCKETS="torch", LIDOG_PEER_ALLREDUCE="0",
+                           LIDOG_SIDE_FORWARD="0", LIDOG_SIDE_BACKWARD="0")
+
+
+_safe_mode()
+
 from . import me, bev, losses, trunk  # noqa: E402,F401
 from .minkunet import make_models  # noqa: E402
 

@@ -112,12 +112,16 @@ class GradientBuckets:
         self.slices = []
         self.issued_early = 0     # buckets reduced while backward was still being queued (hook or trunk executor)
         self.transport = None
+        # LIDOG_DP_SAFE=1 (bench.py's fallback after a hung N > 1 run): no bucket leaves before backward has ended; finish()
+        # reduces them one after the other on the compute stream through torch.distributed -- no bucket stream, no
+        # second communicator in flight next to the statistics messages
+        import os
+        self.deferred = os.environ.get("LIDOG_DP_SAFE") == "1"
         if not self.active:
             return
         from .comm import transport
         self.transport = transport(group)
         if own_communicator is None:
-            import os
             own_communicator = os.environ.get("LIDOG_GRAD_COMM", "shared") == "own"
         if own_communicator and group is None:
             self.group = dist.new_group(ranks=list(range(dist.get_world_size())))
@@ -162,6 +166,8 @@ class GradientBuckets:
             self._reduce(b)
 
     def _reduce(self, b):
+        if self.deferred:      # finish() reduces every bucket
+            return
         lo, hi = self.slices[b]
         buf = self.flat.grad[lo:hi]
         lane = ME.wgrad_lane(buf.device) if buf.is_cuda else None
@@ -185,6 +191,13 @@ class GradientBuckets:
     def finish(self):
         """wait for every bucket; buckets whose hooks did not all fire (unused parameters) are reduced now"""
         if not self.active:
+            return
+        if self.deferred:
+            # the caller (_FlatOptimizer._prepare) has joined the weight-gradient stream: every gradient is complete on
+            # the current stream
+            for lo, hi in self.slices:
+                dist.all_reduce(self.flat.grad[lo:hi], group=self.group)
+            self.pending[:] = self.pending0
             return
         for b, left in enumerate(self.pending.tolist()):
             if left > 0:

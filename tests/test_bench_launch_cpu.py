@@ -140,3 +140,118 @@ def test_no_probe_after_a_failed_run_or_when_switched_off(tmp_path):
     assert p.returncode != 0 and "PROBE RAN" not in p.stderr
     p, _ = _run(tmp_path, _RANK_OK, extra_env={"LIDOG_BENCH_PROBE_SCRIPT": probe, "LIDOG_BENCH_PROBE": "0"})
     assert p.returncode == 0 and "PROBE RAN" not in p.stderr
+
+
+# ---------------------------------------------------------------- every rank of an N > 1 run supervises its own worker
+def _supervise(tmp_path, body, extra_env=None, rank=0, timeout=120, master_port="29511"):
+    """`bench.py --gpus 2` as ONE rank of a foreign launcher's job (RANK / WORLD_SIZE set by hand, no rendezvous needed:
+    the supervisor itself never joins a process group); the worker is a stand-in script"""
+    worker = tmp_path / f"worker{rank}.py"
+    worker.write_text(textwrap.dedent(body))
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=master_port, TORCHELASTIC_RUN_ID="x", LIDOG_BENCH_WORKER_SCRIPT=str(worker), **(extra_env or {}))
+    env.pop("LIDOG_BENCH_WORKER", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=timeout, cwd=str(tmp_path))
+    return p, time.time() - t0
+
+
+_WORKER = """
+    import json, os, sys, time
+    assert os.environ["LIDOG_BENCH_WORKER"] == "1" and sys.argv[1:] == ["--gpus", "2", "--steps", "2", "--warmup", "1"]
+    safe = os.environ.get("LIDOG_DP_SAFE") == "1"
+    sys.stderr.write("worker up\\n"); sys.stderr.flush()
+    if not safe:
+        %s
+    print(json.dumps({"mode": os.environ.get("LIDOG_BENCH_MODE", "normal"), "port": os.environ["MASTER_PORT"],
+                      "elastic": [k for k in os.environ if k.startswith("TORCHELASTIC_")],
+                      "fault": os.environ.get("LIDOG_BENCH_FAULT"), "probe": os.environ.get("LIDOG_BENCH_PROBE")}), flush=True)
+    """
+
+
+def test_supervised_worker_that_finishes_is_relayed_unchanged(tmp_path):
+    p, _ = _supervise(tmp_path, _WORKER % "pass")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["mode"] == "normal" and line["port"] == "29511" and line["elastic"] == ["TORCHELASTIC_RUN_ID"]
+    assert "worker up" in p.stderr
+
+
+def test_silent_worker_is_killed_and_a_safe_mode_worker_prints_the_fallback_line(tmp_path):
+    """a hung first N > 1 run must still produce a line -- marked as the fallback, with a non-zero exit"""
+    p, dt = _supervise(tmp_path, _WORKER % "time.sleep(600)",
+                       extra_env={"LIDOG_BENCH_WATCHDOG_S": "3", "LIDOG_BENCH_FAULT": "bucket_hang:1"})
+    assert p.returncode == 124 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    # fresh rendezvous port (the same on every rank: a function of the launcher's), no launcher agent store, no fault hook
+    assert line["mode"] == "safe-fallback" and line["port"] == str(20000 + (29511 + 7919) % 40000)
+    assert line["elastic"] == [] and line["fault"] is None and line["probe"] == "0"
+    assert "reported nothing for 3 s and was killed" in p.stderr and "safe-mode fallback" in p.stderr
+
+
+def test_both_ranks_derive_the_same_fallback_port(tmp_path):
+    ports = []
+    for rank in (0, 1):
+        p, _ = _supervise(tmp_path, _WORKER % "time.sleep(600)", rank=rank, extra_env={"LIDOG_BENCH_WATCHDOG_S": "2"})
+        ports.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])["port"])
+    assert ports[0] == ports[1] != "29511"
+
+
+def test_a_fallback_that_hangs_too_ends_with_125_and_no_line(tmp_path):
+    p, dt = _supervise(tmp_path, """
+        import time
+        time.sleep(600)
+        """, extra_env={"LIDOG_BENCH_WATCHDOG_S": "2"})
+    assert p.returncode == 125 and dt < 60, (p.returncode, dt)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "went silent too" in p.stderr
+
+
+def test_a_worker_that_exits_is_not_a_hang(tmp_path):
+    p, dt = _supervise(tmp_path, """
+        import sys
+        sys.stderr.write("boom\\n")
+        sys.exit(7)
+        """, extra_env={"LIDOG_BENCH_WATCHDOG_S": "3"})
+    assert p.returncode == 7 and "boom" in p.stderr and "safe-mode" not in p.stderr
+
+
+def test_fallback_can_be_switched_off(tmp_path):
+    p, _ = _supervise(tmp_path, _WORKER % "time.sleep(600)",
+                      extra_env={"LIDOG_BENCH_WATCHDOG_S": "2", "LIDOG_BENCH_FALLBACK": "0"})
+    assert p.returncode == 124 and not p.stdout.strip()
+
+
+def test_sigterm_to_the_supervisor_ends_the_worker(tmp_path):
+    """the launcher tears a job down with SIGTERM: the worker (a process group of its own) must not outlive its supervisor"""
+    import signal
+    worker = tmp_path / "w.py"
+    pidfile = tmp_path / "pid"
+    worker.write_text(textwrap.dedent(f"""
+        import os, time
+        open({str(pidfile)!r}, "w").write(str(os.getpid()))
+        time.sleep(600)
+        """))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="29512", LIDOG_BENCH_WORKER_SCRIPT=str(worker))
+    env.pop("LIDOG_BENCH_WORKER", None)
+    sup = subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    for _ in range(600):
+        if pidfile.exists() and pidfile.read_text():
+            break
+        time.sleep(0.1)
+    pid = int(pidfile.read_text())
+    sup.send_signal(signal.SIGTERM)
+    assert sup.wait(timeout=30) == 128 + signal.SIGTERM
+    for _ in range(100):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(pid, signal.SIGKILL)
+        raise AssertionError("the worker outlived its supervisor")

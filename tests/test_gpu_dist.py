@@ -104,6 +104,14 @@ def test_single_rank_rccl_runs_every_data_parallel_path():
                       "LIDOG_WGRAD_FIT": "0"})
     assert dp["config"]["parallelism"] == "dp1+syncbn" and plain["config"]["parallelism"] == "dp1"
     assert abs(dp["loss"] - plain["loss"]) <= 2e-5 * abs(plain["loss"]), (dp["loss"], plain["loss"])
+    assert dp["config"]["collectives"] == "native" and dp["mode"] == "normal"
+    # the safe mode bench.py falls back to after a hung N > 1 run (LIDOG_DP_SAFE=1: torch.distributed's communicator for
+    # statistics and buckets, buckets after backward, no side streams) computes the same step
+    safe = _bench_line({"LIDOG_BENCH_SINGLE_RANK_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port + 1),
+                        "LIDOG_WGRAD_FIT": "0", "LIDOG_DP_SAFE": "1"})
+    assert safe["config"]["collectives"] == "torch" and "dp_safe" in safe["config"]
+    assert safe["config"]["trunk_path"] == "executor" and safe["replicas_identical"]["parameters"] is True
+    assert abs(safe["loss"] - plain["loss"]) <= 2e-5 * abs(plain["loss"]), (safe["loss"], plain["loss"])
 
 
 def _rccl_c_abi_worker(q):
@@ -348,3 +356,32 @@ def test_ranks_started_by_a_foreign_launcher_run_the_probe_themselves():
     assert probe, out.stderr[-3000:]
     pr = json.loads(probe[-1][probe[-1].index('{"peer_probe"'):])["peer_probe"]
     assert pr["ranks"] == 2 and pr["peer_sum_ok"] is True and pr["us"]["peer_one_shot"] > 0
+
+
+def test_a_hung_two_rank_run_still_produces_a_fallback_line():
+    """rank 1 never issues its first gradient bucket (LIDOG_BENCH_FAULT), rank 0 waits in that
+    all-reduce for ever.  Launched the way the driver launches N > 1 (its own torch.distributed.run line; both ranks on the
+    one GPU over gloo): every rank's supervisor (bench.supervise_rank) ends its silent worker, a fresh pair of workers runs
+    the measurement in safe mode, rank 0 prints THAT line marked "safe-fallback", and the command exits non-zero."""
+    import json
+    import socket
+    import subprocess
+    env = dict(os.environ, LIDOG_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LIDOG_BENCH_FAULT="bucket_hang:1",
+               LIDOG_BENCH_WATCHDOG_S="30")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LIDOG_PEER_ALLREDUCE", "LIDOG_DP_SAFE"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--min-seconds", "0.1", "--batch", "1", "--config", "source8k"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode != 0
+    assert "injected fault" in out.stderr and "was killed" in out.stderr, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (out.stdout, out.stderr[-3000:])
+    line = lines[0]
+    assert line["mode"] == "safe-fallback" and line["n_gpus"] == 2 and "dp_safe" in line["config"]
+    assert line["config"]["collectives"] == "torch" and line["config"]["trunk_path"] == "executor"
+    assert line["replicas_identical"] == {"parameters": True, "syncbn_running_statistics": True}
