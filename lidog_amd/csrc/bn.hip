@@ -320,16 +320,9 @@ static bool colreduce_uses_partials(int C, int64_t hw) { return hw == 1 && C % 4
 #define COLREDUCE_BWD_MAX_BLOCKS 2048
 
 #include <stdlib.h>
-// workgroups of the per-row statistics reductions (forward and backward): LIDOG_STATS_BLOCKS overrides (A/B runs; <= 2048)
-extern "C" int32_t lidog_stats_max_blocks(void) {
-    static int v = 0;
-    if (!v) {
-        const char *e = getenv("LIDOG_STATS_BLOCKS");
-        v = e ? atoi(e) : 1024;   // measured in the step: 1024 (two rows in flight per thread) 50.4 ms, 2048 50.8, 512 50.6
-        if (v < 64 || v > COLREDUCE_BWD_MAX_BLOCKS) v = COLREDUCE_BWD_MAX_BLOCKS;
-    }
-    return v;
-}
+// workgroups of the per-row statistics reductions (forward and backward); measured in the step: 1024 (two rows in flight
+// per thread) 50.4 ms, 2048 50.8, 512 50.6; at bs 2 1536 / 2048 lose too (round 5)
+extern "C" int32_t lidog_stats_max_blocks(void) { return 1024; }
 
 extern "C" int64_t lidog_bn_bwd_reduce_blocks(int64_t n, int32_t C) {
     const int RB = 256 / (C / 4);

@@ -17,7 +17,7 @@ void lidog_set_error(const char *fmt, ...) {
 extern "C" const char *lidog_last_error(void) { return g_err; }
 // bumped whenever an entry point changes its arguments or their meaning (lidog_amd/_lib.py checks it at load time);
 // 4 = round 4: in-kernel statistics finish (workspace sizes), peer all-reduce stream binding / fault hooks
-extern "C" int lidog_abi_version(void) { return 7; }
+extern "C" int lidog_abi_version(void) { return 8; }
 
 extern "C" int64_t lidog_hash_capacity(int64_t n) {
     int64_t cap = 1024;

@@ -33,7 +33,6 @@ __device__ __forceinline__ void frag_load(const float *p, float (&f)[NT]) {
 
 template <int NT>
 __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
-#ifndef LIDOG_CACHED_T_STORE
     // the product rows are written once and read once by the reduction pass: streaming (nontemporal) stores keep them
     // from evicting the gathered feature rows and the weights from L2 (gathered GEMM 3-9 % faster)
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -48,16 +47,6 @@ __device__ __forceinline__ void frag_store(float *p, const float (&f)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) __builtin_nontemporal_store(f[t], p + t);
     }
-#else
-    if constexpr (NT == 4) {
-        *reinterpret_cast<float4 *>(p) = make_float4(f[0], f[1], f[2], f[3]);
-    } else if constexpr (NT == 2) {
-        *reinterpret_cast<float2 *>(p) = make_float2(f[0], f[1]);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) p[t] = f[t];
-    }
-#endif
 }
 
 // ------------------------------------------------------------------ gathered GEMM
@@ -279,18 +268,10 @@ int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B
         return 0;
     }
     // the 96-column kernel fits 128 registers without spilling: four workgroups per CU instead of three, measured in
-    // the training step (same box, alternating): 49.88 / 49.84 -> 49.76 / 49.74 ms; LIDOG_GEMM3_WAVES=1 switches back
-    static int waves3 = -1;
-    if (waves3 < 0) {
-        const char *e = getenv("LIDOG_GEMM3_WAVES");
-        waves3 = (e && atoi(e) == 1) ? 1 : 4;
-    }
+    // the training step (same box, alternating): 49.88 / 49.84 -> 49.76 / 49.74 ms
     switch (nt) {
         case 4: LAUNCH(4, 1); break;
-        case 3:
-            if (waves3 == 4) LAUNCH(3, 4);
-            else LAUNCH(3, 1);
-            break;
+        case 3: LAUNCH(3, 4); break;
         case 2: LAUNCH(2, 1); break;
         default: LAUNCH(1, 1);
     }

@@ -638,21 +638,11 @@ static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const
                   "sconv_os: K <= %d, channel counts multiples of 32 (got K %d, %d -> %d)", OS_MAXK, K, Cin, Cout);
     LIDOG_REQUIRE(A && nbr && perm && wave_masks && tile_order && W && out, "sconv_os: null argument");
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
-    static int force_nt = -1;   // A/B: LIDOG_OS_NT = column tiles of 32 per workgroup where the width allows it
-    if (force_nt < 0) {
-        const char *e = getenv("LIDOG_OS_NT");
-        force_nt = e ? atoi(e) : 0;
-    }
-    if (force_nt >= 1 && force_nt <= 4 && Cout % (32 * force_nt) == 0) nt = force_nt;
     dim3 grid((unsigned)(os_pad(n) / OS_TM), (unsigned)(Cout / (32 * nt)));
     // runs of 4 consecutive tiles of the launch order per XCD (measured in the step, same box, alternating: 48.13 / 48.07 ->
     // 48.07 / 47.99 ms; 2: 48.11 / 47.95; 8: 48.14 / 48.20; 16: 48.23 / 48.35; 64: 50.3 -- the heaviest-first order must
-    // survive); LIDOG_OS_XCD_GROUP=0: plain round-robin
-    static int xcd_group = -1;
-    if (xcd_group < 0) {
-        const char *e = getenv("LIDOG_OS_XCD_GROUP");
-        xcd_group = e ? atoi(e) : 4;
-    }
+    // survive)
+    const int xcd_group = 4;
 #define OS_LAUNCHF(NT_, MW_, F_)                                                                                 \
     k_sconv_os_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, \
                                                         addend, Cin, Cout, out, stats, in_bn, xcd_group)
@@ -667,20 +657,10 @@ static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const
         LIDOG_LAUNCH_CHECK();
         return 0;
     }
-    static int minw = -1;   // A/B: LIDOG_OS_MINW=3 compiles the 96- / 128-column kernels for three waves per SIMD (spills)
-    if (minw < 0) {
-        const char *e = getenv("LIDOG_OS_MINW");
-        minw = e ? atoi(e) : 2;
-    }
+    // (three waves per SIMD for the 96- / 128-column kernels spill: measured slower, round 4)
     switch (nt) {
-        case 4:
-            if (minw >= 3) OS_LAUNCH(4, 3);
-            else OS_LAUNCH(4, 2);
-            break;
-        case 3:
-            if (minw >= 3) OS_LAUNCH(3, 3);
-            else OS_LAUNCH(3, 2);
-            break;
+        case 4: OS_LAUNCH(4, 2); break;
+        case 3: OS_LAUNCH(3, 2); break;
         case 2: OS_LAUNCH(2, 4); break;
         default: OS_LAUNCH(1, 4);
     }

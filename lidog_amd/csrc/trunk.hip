@@ -1082,17 +1082,6 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     return 0;
 }
 
-// A stream whose kernels run on a subset of the compute units (the weight-gradient lane of the backward pass can be kept
-// off part of the chip so that the dependent chain on the launch stream always finds free CUs): mask bit i = CU i of the
-// runtime's enumeration, `words` 32-bit words.  The caller owns the stream (hipStreamDestroy through torch or at exit).
-extern "C" int lidog_stream_create_cu_mask(const uint32_t *mask, int32_t words, void **stream_out) {
-    LIDOG_REQUIRE(mask && words > 0 && stream_out, "stream_create_cu_mask: bad arguments");
-    hipStream_t st;
-    LIDOG_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
-    *stream_out = (void *)st;
-    return 0;
-}
-
 // readers [n_ops]: for every op the op index of the convolution that normalises its output while staging it (fusion 4,
 // in_bn_reader above), -1 where the BatchNorm keeps its own apply pass.  Host only; what the two passes will decide.
 extern "C" int lidog_trunk_in_bn_readers(const int64_t *convs, int32_t n_convs, const int64_t *maps, int32_t n_maps,

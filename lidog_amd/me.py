@@ -181,49 +181,12 @@ _SCONV_OS_MIN_TILES = int(os.environ.get("LIDOG_SCONV_OS_MIN_TILES", "1500"))
 _OS_HINT = {}     # kernel-map key -> the map of the previous batch took the output-stationary kernel
 
 
-# stream priorities of the helper streams (HIP: lower number = served first; the step itself runs on torch's current
-# stream): experiments with LIDOG_LANE_PRIORITY / LIDOG_SIDE_PRIORITY
-_LANE_PRIORITY = int(os.environ.get("LIDOG_LANE_PRIORITY", "0"))
-_SIDE_PRIORITY = int(os.environ.get("LIDOG_SIDE_PRIORITY", "0"))
-
-
 def _side_stream(device):
     """the stream coordinate maps are prepared on when they are built ahead of time (CoordinateManager.prepare)"""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key, priority=_SIDE_PRIORITY)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
     return _SIDE_STREAMS[key]
-
-
-def _masked_stream(device, spec):
-    """A stream restricted to part of the chip's 256 CUs (hipExtStreamCreateWithCUMask), or None for an empty spec.
-    spec: "first:N" (CUs 0 .. N-1 of the runtime's enumeration), "every:K" (every K-th CU), "skip:K" (all but every K-th)
-    or "hex:<mask>" (a 256-bit mask in hex, bit i = CU i).  An experiment hook of the backward pass's second stream
-    (LIDOG_LANE_CU_MASK): the default is an unrestricted stream."""
-    if not spec:
-        return None
-    kind, _, arg = spec.partition(":")
-    n_cus = 256
-    if kind == "first":
-        bits = [i < int(arg) for i in range(n_cus)]
-    elif kind == "every":
-        bits = [i % int(arg) == 0 for i in range(n_cus)]
-    elif kind == "skip":
-        bits = [i % int(arg) != 0 for i in range(n_cus)]
-    elif kind == "hex":
-        v = int(arg, 16)
-        bits = [(v >> i) & 1 == 1 for i in range(n_cus)]
-    else:
-        raise ValueError(f"CU mask {spec!r}: expected first:N, every:K, skip:K or hex:<mask>")
-    words = (ctypes.c_uint32 * (n_cus // 32))()
-    for i, b in enumerate(bits):
-        if b:
-            words[i // 32] |= 1 << (i % 32)
-    out = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        if _lib.load().lidog_stream_create_cu_mask(words, n_cus // 32, ctypes.byref(out)) != 0:
-            raise RuntimeError(_lib.load().lidog_last_error().decode())
-    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 class _WgradLane:
@@ -253,8 +216,7 @@ class _WgradLane:
 
     def __init__(self, device):
         self.device = device
-        self.stream = _masked_stream(device, os.environ.get("LIDOG_LANE_CU_MASK", "")) or \
-            torch.cuda.Stream(device=device, priority=_LANE_PRIORITY)
+        self.stream = torch.cuda.Stream(device=device)
         self.raw = self.stream.cuda_stream    # hipStream_t: kernels are launched on it without switching torch's stream
         self.keep = []
         self.pending = False
@@ -747,13 +709,13 @@ _SUBSET_MAPS = os.environ.get("LIDOG_MAP_SUBSET", "1") != "0"     # A/B switch: 
 # occupancy bitmaps in front of the kernel maps' hash probes (CoordinateManager._bitmap); 0 = plain probes
 _BITMAPS = os.environ.get("LIDOG_MAP_BITMAPS", "1") != "0"
 _BITMAP_MAX_BYTES = int(os.environ.get("LIDOG_MAP_BITMAP_MAX_MB", "1024")) << 20
-_BITMAP_MIN_ROWS = int(os.environ.get("LIDOG_MAP_BITMAP_MIN_ROWS", "40000"))
+_BITMAP_MIN_ROWS = 40000
 
 
 # workgroups of one weight-gradient launch (8 per CU), measured optimum on MI355X (LIDOG_WGRAD_BLOCKS: A/B runs)
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("LIDOG_WGRAD_BLOCKS", "2048"))
-# the >= 256 x 256 layers (few pairs, 256 KB partial slots): A/B switch
-_WGRAD_WIDE_BLOCKS = int(os.environ.get("LIDOG_WGRAD_WIDE_BLOCKS", str(_WGRAD_TARGET_BLOCKS // 2)))
+# the >= 256 x 256 layers (few pairs, 256 KB partial slots): half of that (round 5: 2 048 -> 1 024 halved their slot traffic)
+_WGRAD_WIDE_BLOCKS = _WGRAD_TARGET_BLOCKS // 2
 
 
 # LIDOG_WGRAD_FIT: 1 = the work items of a launch fill a whole number of rounds of the kernel's slots (see _wgrad_chunk;
@@ -798,6 +760,7 @@ def _wgrad_chunk(k_off_host, Cin, Cout):
         rounds = -(-blocks // slots) if fit == 2 else max(1, int(blocks / slots + 0.5))
         budget = min(max(1, rounds * slots // tiles), max_items)
         cnt = np.diff(np.asarray(k_off_host, dtype=np.int64))
+        budget = max(budget, int(np.count_nonzero(cnt)))    # every non-empty offset costs at least one item
         chunk = max(128, (-(-P // budget) + 31) // 32 * 32)
         while int(np.sum((cnt + chunk - 1) // chunk)) > budget:
             chunk += 32
@@ -807,8 +770,10 @@ def _wgrad_chunk(k_off_host, Cin, Cout):
     return (chunk + 31) // 32 * 32
 
 
-_WGRAD_ORDER = int(os.environ.get("LIDOG_WGRAD_ORDER", "2"))
-_WGRAD_GROUP = int(os.environ.get("LIDOG_WGRAD_GROUP", "32"))
+# launch order of the work items (csrc/hostprep.hip): 2 = items at the same relative position of their offsets together,
+# in groups of 32 that land on one XCD (rounds 2-3 measured 0 = by offset and 1 = interleaved as slower)
+_WGRAD_ORDER = 2
+_WGRAD_GROUP = 32
 
 
 def _wgrad_items_host(k_off_host, chunk):

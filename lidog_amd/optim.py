@@ -93,7 +93,7 @@ class GradientBuckets:
     and the main stream never waits before finish().
     RCCL executes the collectives of ONE communicator in issue order on one stream, so a bucket that still waits for
     the lane holds back the SyncBatchNorm statistics all-reduces issued after it -- by at most the lane's lag of about
-    one layer.  `LIDOG_GRAD_COMM=own` gives the buckets a communicator of their own (`dist.new_group`) and removes
+    one layer.  `own_communicator=True` gives the buckets a communicator of their own (`dist.new_group`) and removes
     that coupling; it is not the default because two communicators in flight at once could not be exercised on more
     than one rank in this build's environment, and a same-communicator schedule is identical on every rank by
     construction."""
@@ -121,8 +121,6 @@ class GradientBuckets:
             return
         from .comm import transport
         self.transport = transport(group)
-        if own_communicator is None:
-            own_communicator = os.environ.get("LIDOG_GRAD_COMM", "shared") == "own"
         if own_communicator and group is None:
             self.group = dist.new_group(ranks=list(range(dist.get_world_size())))
         cur_lo = cur_hi = flat.total

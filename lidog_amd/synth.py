@@ -83,30 +83,6 @@ def mix3d_voxels(seed, config="nusc35k"):
     return vox[first], lab[first]
 
 
-def _row_order(coords, kind):
-    """permutation of the rows of a collated batch: 'morton' (scan by scan, Z-order of (x, y, z)), 'xyz' (lexicographic),
-    'random'"""
-    b = coords[:, 0].astype(np.int64)
-    if kind == "random":
-        key = np.random.default_rng(0).permutation(len(coords))
-        return np.lexsort((key, b))
-    u = (coords[:, 1:4].astype(np.int64) + (1 << 15))
-    if kind == "xyz":
-        return np.lexsort((u[:, 2], u[:, 1], u[:, 0], b))
-    if kind in ("morton", "morton_xy"):
-        def spread(v, step):
-            out = np.zeros_like(v)
-            for i in range(17):
-                out |= ((v >> i) & 1) << (step * i)
-            return out
-        if kind == "morton":
-            code = spread(u[:, 0], 3) | (spread(u[:, 1], 3) << 1) | (spread(u[:, 2], 3) << 2)
-        else:   # Z-order in the ground plane, height last
-            code = ((spread(u[:, 0], 2) | (spread(u[:, 1], 2) << 1)) << 17) | u[:, 2]
-        return np.lexsort((code, b))
-    raise ValueError(kind)
-
-
 def make_batch(seeds, config="kitti120k", device="cpu", bev_size=167, mix3d=False):
     """Collated batch with the keys of CollateFNSingleSourceBEVMultiLevel (collation.py:318-325)."""
     coords, labels = [], []
@@ -115,10 +91,6 @@ def make_batch(seeds, config="kitti120k", device="cpu", bev_size=167, mix3d=Fals
         coords.append(np.concatenate([np.full((v.shape[0], 1), b, np.int32), v], axis=1))
         labels.append(l)
     coords, labels = np.concatenate(coords), np.concatenate(labels)
-    order = os.environ.get("LIDOG_SYNTH_ROW_ORDER", "")   # experiment: rows of a batch in another order (same voxels)
-    if order:
-        perm = _row_order(coords, order)
-        coords, labels = coords[perm], labels[perm]
     coords = torch.from_numpy(coords).to(device)
     labels = torch.from_numpy(labels).long().to(device)
     rng = np.random.default_rng(1000003 + int(seeds[0]))

@@ -260,7 +260,7 @@ def test_shared_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/lidog_amd.h but not exported"
     assert declared - {"lidog_last_error"} == set(_lib.SIGNATURES), "python binding and header disagree"
-    assert lib.lidog_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.lidog_abi_version() == _lib.ABI_VERSION == 8
     lib.lidog_hash_capacity.restype = ctypes.c_int64
     assert lib.lidog_hash_capacity(ctypes.c_int64(1000)) == 2048
 
