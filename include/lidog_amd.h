@@ -113,10 +113,18 @@ int lidog_kernel_map_rows(const int32_t *pos, int64_t n, int32_t K, int32_t mark
  * B is [K, Cin, Cout] row-major.  dst(p) = p when scatter == NULL, else scatter[p] (each destination
  * written once).  The product of one row is an fmaf chain over ci ascending starting from 0
  * (bit-identical to oracle/me_oracle.c:orc_conv_fwd before its scatter-add).
- * bias (may be NULL) [Cout] is added after the chain. */
+ * bias (may be NULL) [Cout] is added after the chain.
+ * a_rows: rows of A (every gather index, or every p when gather == NULL, is below it); 0 = not known.  Only a hint for
+ * the choice of kernel (an A below 4 GiB lets a workgroup walk several tiles with 32-bit row offsets); never read as a bound. */
 int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
                      const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles,
-                     int32_t Cin, int32_t Cout, float *T, const int32_t *scatter, void *stream);
+                     int32_t Cin, int32_t Cout, float *T, const int32_t *scatter, int64_t a_rows, void *stream);
+/* The matrix-core gathered GEMM gives a workgroup several (tile, column tile) units -- the next unit's rows are fetched
+ * while the current one is multiplied -- when a launch is more than one round of resident workgroups, A is below 4 GiB
+ * (a_rows known) and there is neither a scatter index nor a bias; results are bit-identical either way.  multi: 1 / 0 =
+ * on / off (< 0: unchanged; default on, LIDOG_GEMM_MULTI=0 in the environment turns it off); slots > 0: plan as if that
+ * many workgroups were resident (0: ask the device).  Returns the previous `multi`. */
+int32_t lidog_sconv_gemm_units(int32_t multi, int32_t slots);
 /* T = addend + product of the same gathered GEMM, narrow inputs only (Cin <= 8, Cout % 4 == 0): the data gradient of the
  * classifier `final` (minkunet_bev.py:118-123, 7 -> 96) lands on rows that already hold the BEV head's gradient.  Same
  * bits as lidog_sconv_gemm + lidog_add(addend, product).  Returns 3 for other shapes (nothing launched). */
@@ -470,7 +478,8 @@ int lidog_sconv_os_stats(const float *A, const int32_t *nbr, int64_t n, int32_t 
 int lidog_sconv_gemm_in_bn(const float *A, const int32_t *gather, const float *B, const float *bias,
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int32_t n_tiles,
                            int32_t Cin, int32_t Cout, float *T, const int32_t *scatter, const float *in_mean,
-                           const float *in_invstd, const float *in_w, const float *in_b, int32_t in_relu, void *stream);
+                           const float *in_invstd, const float *in_w, const float *in_b, int32_t in_relu, int64_t a_rows,
+                           void *stream);
 int lidog_sconv_os_stats_in_bn(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
                                const uint32_t *wave_masks, const int32_t *tile_order, const float *W, const float *bias,
                                int32_t Cin, int32_t Cout, float *out, double *sums, double *ws, double count, float eps,

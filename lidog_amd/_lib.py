@@ -25,7 +25,8 @@ SIGNATURES = {
     "lidog_bitmap_set": [_p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p],
     "lidog_kernel_map_bits": [_p, _i64, _p, _p, _i64, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p],
     "lidog_kernel_map_pairs": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
-    "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p],
+    "lidog_sconv_gemm_units": [_i32, _i32],
+    "lidog_sconv_gemm": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _i64, _p],
     "lidog_sconv_gemm_addend": [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce": [_p, _p, _i64, _i32, _i32, _p, _p, _p, _p],
     "lidog_sconv_reduce_stats_ws": [_i64, _i32],
@@ -46,7 +47,7 @@ SIGNATURES = {
     "lidog_sconv_os_bn": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p, _p],
     "lidog_sconv_os_stats": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p, _p],
     "lidog_sconv_wgrad": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p],
-    "lidog_sconv_gemm_in_bn": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],
+    "lidog_sconv_gemm_in_bn": [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _i64, _p],
     "lidog_sconv_os_stats_in_bn": [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _d, _f, _f, _p, _p, _p, _p,
                                    _p, _p, _p, _p, _i32, _p],
     "lidog_sconv_wgrad_in_bn": [_p, _p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p],

@@ -11,6 +11,7 @@
 //          parity classes, each with only its 1/2/2/4 contributing taps -> no wasted FLOPs)
 //   WGRAD  i = co, k = (b,yo,xo),  j = (ci,ky,kx)   A = gY[co][k]          B = im2col(X)^T, split over k
 #include "common.h"
+#include "clock_stamp.h"
 
 #include "conv2d.h"
 
@@ -365,7 +366,9 @@ __global__ __launch_bounds__(256) void k_conv_s2(IgClasses pc) {
     const IgParams p = pc.c[cls];
     const int r = x - pc.first[cls];
     const int rt = pc.row_tiles[cls];
+    LIDOG_STAMP_BEGIN()
     conv_s2_tile<MODE, WM, TI, TJ>(p, r / rt, r % rt, As, Bs);
+    LIDOG_STAMP_END()
 }
 
 // ------------------------------------------------------------------ weight repack for DGRAD

@@ -303,13 +303,13 @@ extern "C" int lidog_sconv_gemm_in_bn(const float *A, const int32_t *gather, con
                                       const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows,
                                       int32_t n_tiles, int32_t Cin, int32_t Cout, float *T, const int32_t *scatter,
                                       const float *in_mean, const float *in_invstd, const float *in_w, const float *in_b,
-                                      int32_t in_relu, void *stream) {
+                                      int32_t in_relu, int64_t a_rows, void *stream) {
     if (n_tiles == 0) return 0;
     LIDOG_REQUIRE(in_mean && in_invstd && in_w && in_b, "sconv_gemm_in_bn: input BatchNorm vectors missing");
     LIDOG_REQUIRE(g_sparse_core == 1 && Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 32 == 0,
                   "sconv_gemm_in_bn: matrix-core kernels only (channel counts multiples of 32; got %d -> %d)", Cin, Cout);
     lidog_launch_gemm_mfma(A, gather, B, bias, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, scatter,
-                           InBn{in_mean, in_invstd, in_w, in_b, in_relu}, (hipStream_t)stream);
+                           InBn{in_mean, in_invstd, in_w, in_b, in_relu}, a_rows, (hipStream_t)stream);
     LIDOG_LAUNCH_CHECK();
     return 0;
 }
@@ -317,13 +317,13 @@ extern "C" int lidog_sconv_gemm_in_bn(const float *A, const int32_t *gather, con
 extern "C" int lidog_sconv_gemm(const float *A, const int32_t *gather, const float *B, const float *bias,
                                 const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows,
                                 int32_t n_tiles, int32_t Cin, int32_t Cout, float *T, const int32_t *scatter,
-                                void *stream) {
+                                int64_t a_rows, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_tiles == 0) return 0;
     LIDOG_REQUIRE(Cin > 0 && Cout > 0, "sconv_gemm: bad channel counts %d %d", Cin, Cout);
     if (g_sparse_core == 1 && Cin % 32 == 0 && Cout % 32 == 0) {
         lidog_launch_gemm_mfma(A, gather, B, bias, tile_k, tile_row0, tile_rows, n_tiles, Cin, Cout, T, scatter,
-                               InBn{nullptr, nullptr, nullptr, nullptr, 0}, st);
+                               InBn{nullptr, nullptr, nullptr, nullptr, 0}, a_rows, st);
         LIDOG_LAUNCH_CHECK();
         return 0;
     }

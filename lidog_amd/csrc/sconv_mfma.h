@@ -24,7 +24,8 @@ __device__ __forceinline__ float4 in_bn_apply(float4 v, const float4 &m, const f
 
 int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B, const float *bias,
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
-                           int Cin, int Cout, float *T, const int32_t *scatter, InBn in_bn, hipStream_t st);
+                           int Cin, int Cout, float *T, const int32_t *scatter, InBn in_bn, int64_t a_rows, hipStream_t st);
+void lidog_gemm_multi_suspend(int delta);
 int lidog_launch_wgrad_mfma(const float *A, const int32_t *pa, const float *G, const int32_t *pg,
                             const int32_t *items, int n_items, int Cin, int Cout, float *partial, InBn in_bn,
                             hipStream_t st);

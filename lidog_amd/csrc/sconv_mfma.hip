@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "sconv_mfma.h"
+#include "clock_stamp.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
     const int col0 = blockIdx.y * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
+    LIDOG_STAMP_BEGIN()
 
     // With a scatter index the destination rows go through LDS (every lane of the epilogue needs 16 of them); without
     // one they are row0 + r, and the gather indices are then fetched by the lanes that use them (8 lanes share an
@@ -244,16 +246,295 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma(const float *__re
             frag_store<NT>(out, v);
         }
     }
+    LIDOG_STAMP_END()
+}
+
+// ------------------------------------------------------------------ gathered GEMM, several units per workgroup
+// Round 6 (profiles/r06_stalls_bs4_by_shape.txt): the waves of the kernel above spend 59-78 % of their cycles stalled at
+// instruction issue behind the matrix pipe and only 13-25 % parked on memory or barriers, yet the pipe is busy 0.47-0.78
+// of the time: what is missing is not bandwidth but matrix work to issue while a workgroup walks its dependent
+// prologue (tile descriptor -> gather indices -> rows: three memory round trips before the first MFMA) and its epilogue.
+// With one unit (a 128-row tile x 32 NT columns) per workgroup that is paid once per 4-12 chunks of MFMA work, by every
+// workgroup of a round at the same time.  Here a workgroup owns units u, u + G, u + 2G, ... (G = gridDim.x) and the
+// loop over 32-channel chunks simply runs on into the next unit: its descriptor and gather indices are fetched one unit
+// ahead, its first chunk by the prefetch of the current unit's last chunk.  Per unit the arithmetic, its order and
+// the stores are those of k_sconv_gemm_mfma: identical bits.  No scatter index, no bias (the launcher keeps the
+// one-unit kernel for those).
+template <int NT, int MINW = 1, bool FOLD = false>
+__global__ __launch_bounds__(256, MINW) void k_sconv_gemm_mfma_ms(const float *__restrict__ A,
+                                                            const int32_t *__restrict__ gather,
+                                                            const float *__restrict__ B,
+                                                            const int32_t *__restrict__ tile_k,
+                                                            const int32_t *__restrict__ tile_row0,
+                                                            const int32_t *__restrict__ tile_rows, int n_tiles,
+                                                            int n_units, int Cin, int Cout, float *__restrict__ T,
+                                                            InBn in_bn) {
+    constexpr int TN = 32 * NT;
+    constexpr int BV = (MG_BK * TN / 4) / 256;  // float4 of B per thread per chunk (1..4)
+    __shared__ float As[MG_TM * MG_SA];
+    __shared__ __attribute__((aligned(16))) float Bs[MG_BK * TN];
+
+    const int G = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    LIDOG_STAMP_BEGIN()
+    const uint32_t q4 = (tid & 7) * 4;
+    const char *Ab = reinterpret_cast<const char *>(A);
+
+    // unit u = (tile u % n_tiles, column tile u / n_tiles): the order of the one-unit kernel's grid (x fastest)
+    int u = blockIdx.x;
+    int tile = u % n_tiles;
+    int row0 = tile_row0[tile], rows = tile_rows[tile], col0 = (u / n_tiles) * TN;
+    const float *Bk = B + (size_t)tile_k[tile] * Cin * Cout + col0;
+    // BYTE offsets, 32 bits (the launcher takes this kernel only for an A below 4 GiB: 64-bit row pointers for two units
+    // do not fit the registers of three workgroups per CU), of the 4 gathered rows this thread stages (8 lanes fetch one
+    // 128-B line of a row); rows past the end of the tile read the tile's first row and are never stored
+    uint32_t a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = (tid + 256 * j) >> 3;
+        r = r < rows ? r : 0;
+        uint32_t src = gather ? (uint32_t)gather[row0 + r] : (uint32_t)(row0 + r);
+        a_off[j] = (src * (uint32_t)Cin + q4) * 4u;
+    }
+    // the unit after this one (the current one again when there is none: its loads are then redundant re-reads, as the
+    // one-unit kernel's last prefetch)
+    int un = u + G;
+    bool has_next = un < n_units;
+    int unc = has_next ? un : u;
+    int ntile = unc % n_tiles;
+    int nrow0 = tile_row0[ntile], nrows = tile_rows[ntile], ncol0 = (unc / n_tiles) * TN;
+    const float *Bkn = B + (size_t)tile_k[ntile] * Cin * Cout + ncol0;
+    uint32_t n_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = (tid + 256 * j) >> 3;
+        r = r < nrows ? r : 0;
+        uint32_t src = gather ? (uint32_t)gather[nrow0 + r] : (uint32_t)(nrow0 + r);
+        n_off[j] = (src * (uint32_t)Cin + q4) * 4u;
+    }
+
+    float4 ra[4], rb0, rb1, rb2, rb3;
+    float4 pm, ps, pw, pb;
+    pm = ps = pw = pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define MS_LOADB(J, R)                                                                  \
+    if constexpr (BV > J) {                                                             \
+        int f = tid + 256 * J;                                                          \
+        int kk = f / (TN / 4), c4 = f % (TN / 4);                                       \
+        R = *reinterpret_cast<const float4 *>(pB + (size_t)kk * Cout + c4 * 4);         \
+    }
+#define MS_STOREB(J, R) \
+    if constexpr (BV > J) *reinterpret_cast<float4 *>(&Bs[(tid + 256 * J) * 4]) = R;
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int f = tid + 256 * j;
+            int r = f >> 3, q = f & 7;
+            const int o = r * MG_SA + q * 4;
+            float4 v = ra[j];
+            if constexpr (FOLD) v = in_bn_apply(v, pm, ps, pw, pb, in_bn.relu);
+            As[o] = v.x;
+            As[o + 1] = v.y;
+            As[o + 2] = v.z;
+            As[o + 3] = v.w;
+        }
+        MS_STOREB(0, rb0) MS_STOREB(1, rb1) MS_STOREB(2, rb2) MS_STOREB(3, rb3)
+    };
+    // o0..o3: byte offsets of this thread's four rows at the chunk's first channel; pB: the chunk's first weight row;
+    // chan: the chunk's first channel (FOLD vectors)
+#define MS_LOAD_CHUNK(O0, O1, O2, O3, PB, CHAN)                                         \
+    {                                                                                   \
+        const float *pB = (PB);                                                         \
+        ra[0] = *reinterpret_cast<const float4 *>(Ab + (O0));                           \
+        ra[1] = *reinterpret_cast<const float4 *>(Ab + (O1));                           \
+        ra[2] = *reinterpret_cast<const float4 *>(Ab + (O2));                           \
+        ra[3] = *reinterpret_cast<const float4 *>(Ab + (O3));                           \
+        if constexpr (FOLD) {                                                           \
+            const int c = (CHAN) + (int)q4;                                             \
+            pm = *reinterpret_cast<const float4 *>(in_bn.mean + c);                     \
+            ps = *reinterpret_cast<const float4 *>(in_bn.invstd + c);                   \
+            pw = *reinterpret_cast<const float4 *>(in_bn.w + c);                        \
+            pb = *reinterpret_cast<const float4 *>(in_bn.b + c);                        \
+        }                                                                               \
+        MS_LOADB(0, rb0) MS_LOADB(1, rb1) MS_LOADB(2, rb2) MS_LOADB(3, rb3)             \
+    }
+
+    f32x16 acc[NT];
+    MS_LOAD_CHUNK(a_off[0], a_off[1], a_off[2], a_off[3], Bk, 0)
+    while (true) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        for (int kb = 0; kb < Cin; kb += MG_BK) {
+            __syncthreads();
+            store_chunk();
+            __syncthreads();
+            // unconditional prefetch: the unit's next chunk, or -- behind its last chunk -- the first chunk of the next unit
+            {
+                const bool last = kb + MG_BK >= Cin;
+                const int chan = last ? 0 : kb + MG_BK;
+                const uint32_t cb = (uint32_t)chan * 4u;
+                MS_LOAD_CHUNK(last ? n_off[0] : a_off[0] + cb, last ? n_off[1] : a_off[1] + cb,
+                              last ? n_off[2] : a_off[2] + cb, last ? n_off[3] : a_off[3] + cb,
+                              last ? Bkn : Bk + (size_t)chan * Cout, chan)
+            }
+            const float *arow = &As[(wave * 32 + li) * MG_SA + kh];
+            const float *bcol = &Bs[kh * TN + li * NT];
+            float bq0[NT], bq1[NT], bn0[NT], bn1[NT], a0, a1, an0, an1;
+            frag_load<NT>(bcol, bq0);
+            frag_load<NT>(bcol + 2 * TN, bq1);
+            a0 = arow[0];
+            a1 = arow[2];
+#pragma unroll
+            for (int j = 0; j < MG_BK / 4; ++j) {
+                if (j + 1 < MG_BK / 4) {
+                    frag_load<NT>(bcol + (4 * j + 4) * TN, bn0);
+                    frag_load<NT>(bcol + (4 * j + 6) * TN, bn1);
+                    an0 = arow[4 * j + 4];
+                    an1 = arow[4 * j + 6];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq0[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq1[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < MG_BK / 4) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        bq0[t] = bn0[t];
+                        bq1[t] = bn1[t];
+                    }
+                    a0 = an0;
+                    a1 = an1;
+                }
+            }
+        }
+        // epilogue of the unit (see k_sconv_gemm_mfma: nothing but the stores themselves may be pending in vmcnt; the next
+        // unit's first chunk was requested a whole MFMA phase ago)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (r < rows) {
+                float *out = T + (size_t)(row0 + r) * Cout + col0 + li * NT;
+                float v[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = acc[t][e];
+                frag_store<NT>(out, v);
+            }
+        }
+        if (!has_next) break;
+        // the next unit becomes the current one; fetch the descriptor and the gather indices of the one after it
+        u = un;
+        row0 = nrow0;
+        rows = nrows;
+        col0 = ncol0;
+        Bk = Bkn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_off[j] = n_off[j];
+        un = u + G;
+        has_next = un < n_units;
+        unc = has_next ? un : u;
+        ntile = unc % n_tiles;
+        nrow0 = tile_row0[ntile];
+        nrows = tile_rows[ntile];
+        ncol0 = (unc / n_tiles) * TN;
+        Bkn = B + (size_t)tile_k[ntile] * Cin * Cout + ncol0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int r = (tid + 256 * j) >> 3;
+            r = r < nrows ? r : 0;
+            uint32_t src = gather ? (uint32_t)gather[nrow0 + r] : (uint32_t)(nrow0 + r);
+            n_off[j] = (src * (uint32_t)Cin + q4) * 4u;
+        }
+    }
+#undef MS_LOADB
+#undef MS_STOREB
+#undef MS_LOAD_CHUNK
+    LIDOG_STAMP_END()
+}
+
+static int g_gemm_multi = -1, g_gemm_slots = 0, g_gemm_suspend = 0;
+// Callers that are about to run the gathered GEMM NEXT TO another stream's matrix kernels (the executor's backward pass
+// with its weight-gradient stream) suspend the several-units form for that span: its workgroups live as long as the
+// launch, so the ones that find their slot taken by the other stream's workgroups start late and finish late -- measured
+// in the two-stream training step 47.50 / 47.73 -> 47.91 / 47.85 ms with it on everywhere, against 6.6 % less kernel time
+// alone (profiles/r06_ab_gemm_units_in_step.txt).  Nestable; host-side state like lidog_sconv_gemm_units.
+void lidog_gemm_multi_suspend(int delta) { g_gemm_suspend += delta; }
+
+// multi: 1 / 0 = several units per workgroup on / off (< 0: leave as it is); slots > 0: plan the units as if that many
+// workgroups were resident (0 = ask the device) -- lets tests walk many units per workgroup on small inputs.  Returns the
+// previous `multi`.
+extern "C" int32_t lidog_sconv_gemm_units(int32_t multi, int32_t slots) {
+    const int32_t old = g_gemm_multi < 0 ? 1 : g_gemm_multi;
+    if (multi >= 0) g_gemm_multi = multi;
+    g_gemm_slots = slots > 0 ? slots : 0;
+    return old;
+}
+
+// resident workgroups of a kernel on the current device (occupancy x compute units), cached per kernel
+template <typename K>
+static int gemm_slots(K kernel, int *cache) {
+    if (*cache <= 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        *cache = per_cu * cus;
+    }
+    return *cache;
 }
 
 int lidog_launch_gemm_mfma(const float *A, const int32_t *gather, const float *B, const float *bias,
                            const int32_t *tile_k, const int32_t *tile_row0, const int32_t *tile_rows, int n_tiles,
-                           int Cin, int Cout, float *T, const int32_t *scatter, InBn in_bn, hipStream_t st) {
+                           int Cin, int Cout, float *T, const int32_t *scatter, InBn in_bn, int64_t a_rows, hipStream_t st) {
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
     // (Round 5: 256-column workgroups for the 256-channel layers -- eight MFMA column tiles per wave, the 128 gathered rows
     // of a tile staged once instead of by two workgroups; 248 registers, two workgroups per CU, bit-identical -- measured in
     // the step, same box, alternating: 47.92 / 47.96 -> 48.21 / 48.15 ms.  Not kept.)
     dim3 grid((unsigned)n_tiles, (unsigned)(Cout / (32 * nt)));
+    // several units per workgroup (k_sconv_gemm_mfma_ms) where a launch is more than one round of resident workgroups: as
+    // many workgroups as are resident, unit u + i G for workgroup u (measured against "the fewest workgroups that need the
+    // same number of rounds", which leaves CUs with unequal numbers of workgroups: bs 4 sum of 14 layer shapes 2.79 ->
+    // 2.69 ms with that, 2.60 ms with every slot filled; profiles/r06_gemm_units.txt).  LIDOG_GEMM_MULTI=0: one unit per
+    // workgroup.
+    if (g_gemm_multi < 0) {
+        const char *e = getenv("LIDOG_GEMM_MULTI");
+        g_gemm_multi = e ? atoi(e) : 1;
+    }
+    const int multi = g_gemm_multi && g_gemm_suspend <= 0, slots_override = g_gemm_slots;
+    if (multi && !scatter && !bias && a_rows > 0 && a_rows * (int64_t)Cin * 4 < ((int64_t)1 << 32)) {
+        const int64_t n_units = (int64_t)n_tiles * (Cout / (32 * nt));
+#define LAUNCHMS(NT_, MW_, F_)                                                                                       \
+    {                                                                                                                \
+        static int slots = 0;                                                                                        \
+        const int s_ = slots_override > 0 ? slots_override : gemm_slots(k_sconv_gemm_mfma_ms<NT_, MW_, F_>, &slots); \
+        if (n_units > s_) {                                                                                          \
+            k_sconv_gemm_mfma_ms<NT_, MW_, F_><<<dim3((unsigned)s_), 256, 0, st>>>(                                   \
+                A, gather, B, tile_k, tile_row0, tile_rows, n_tiles, (int)n_units, Cin, Cout, T, in_bn);             \
+            return 0;                                                                                                \
+        }                                                                                                            \
+    }
+        if (in_bn.mean) {
+            switch (nt) {
+                case 4: LAUNCHMS(4, 3, true); break;
+                case 3: LAUNCHMS(3, 3, true); break;
+                case 2: LAUNCHMS(2, 3, true); break;
+                default: LAUNCHMS(1, 4, true);
+            }
+        } else {
+            switch (nt) {
+                case 4: LAUNCHMS(4, 3, false); break;
+                case 3: LAUNCHMS(3, 4, false); break;
+                case 2: LAUNCHMS(2, 4, false); break;
+                default: LAUNCHMS(1, 4, false);
+            }
+        }
+#undef LAUNCHMS
+    }
 #define LAUNCHF(NT_, MW_, F_)                                                                                     \
     k_sconv_gemm_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, gather, B, bias, tile_k, tile_row0, tile_rows, Cin, Cout, \
                                                           T, scatter, in_bn)
@@ -313,6 +594,7 @@ __global__ __launch_bounds__(64 * NW, (FOLD && MT * NT == 16) ? 3 : 1) void k_sc
     const int ci0 = (blockIdx.y / tiles_n) * TM, co0 = (blockIdx.y % tiles_n) * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
+    LIDOG_STAMP_BEGIN()
     const int grp = wave / WPG, wig = wave % WPG;
     const int64_t p0 = items[n_items + item], p1 = items[2 * n_items + item];
 
@@ -463,6 +745,7 @@ __global__ __launch_bounds__(64 * NW, (FOLD && MT * NT == 16) ? 3 : 1) void k_sc
             dst[(size_t)ci * Cout + co0 + 32 * nj + li] = acc[t][e];
         }
     }
+    LIDOG_STAMP_END()
 }
 
 // Round 5, built and measured for the 96 x 96 case, not kept:

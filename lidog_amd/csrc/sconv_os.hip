@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "clock_stamp.h"
 #include "sconv_mfma.h"
 #include "stats_tail.h"
 
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
     const int col0 = blockIdx.y * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
+    LIDOG_STAMP_BEGIN()
 
     const uint32_t wm = wave_masks[tile * 4 + wave];
     const uint32_t tm = wave_masks[tile * 4] | wave_masks[tile * 4 + 1] | wave_masks[tile * 4 + 2] | wave_masks[tile * 4 + 3];
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
         }
     }
     os_epilogue<NT>(acc, bv, s_row, reinterpret_cast<double *>(As), tile, col0, Cout, addend, out, st);
+    LIDOG_STAMP_END()
 }
 
 static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const int32_t *perm,

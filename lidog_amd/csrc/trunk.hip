@@ -18,6 +18,8 @@
 
 #include "common.h"
 
+void lidog_gemm_multi_suspend(int delta);   // sconv_mfma.hip
+
 namespace {
 
 // ---- table layouts (int64 rows; python fills them as numpy arrays, lidog_amd/trunk.py)
@@ -317,9 +319,9 @@ int gemm(const Ctx &ctx, const int64_t *m, const float *A, int64_t n_src, const 
     }
     int rc = in_bn ? lidog_sconv_gemm_in_bn(in_bn->pre, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2),
                                             (int32_t)m[TM_NTILES], Cin, Cout, out, scatter, in_bn->mean, in_bn->invstd,
-                                            in_bn->w, in_bn->b, 1, st)
+                                            in_bn->w, in_bn->b, 1, n_src, st)
                    : lidog_sconv_gemm(A, gather, B, bias, tile_row(m, 0), tile_row(m, 1), tile_row(m, 2),
-                                      (int32_t)m[TM_NTILES], Cin, Cout, out, scatter, st);
+                                      (int32_t)m[TM_NTILES], Cin, Cout, out, scatter, n_src, st);
     if (rc) return rc;
     if (g_timing) {
         LIDOG_CHECK_HIP(hipEventRecord(rec.e1, (hipStream_t)st));
@@ -670,6 +672,13 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     Bump ga{(char *)garena, 0, garena_bytes, 0, ctx.dry}, sc{(char *)scratch, 0, scratch_bytes, 0, ctx.dry},
         ls{(char *)lane_scratch, 0, lane_bytes, 0, ctx.dry};
     hipStream_t main_st = (hipStream_t)stream, lane_st = (hipStream_t)lane;
+    // the data gradients' gathered GEMMs run next to the lane's weight gradients: one unit per workgroup there
+    // (sconv_mfma.hip:lidog_gemm_multi_suspend)
+    struct MultiUnitGuard {
+        bool on;
+        explicit MultiUnitGuard(bool o) : on(o) { if (on) lidog_gemm_multi_suspend(1); }
+        ~MultiUnitGuard() { if (on) lidog_gemm_multi_suspend(-1); }
+    } multi_unit_guard(lane_st != nullptr && !ctx.dry);
     if (!ctx.dry && dp.sync_bn())
         if (int rc = dp.bind(stream)) return rc;
     hipEvent_t *events = nullptr;

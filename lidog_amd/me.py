@@ -699,7 +699,7 @@ def _gemm(A, gather, B, bias, m, Cin, Cout, out, scatter, tiles=None):
     """`tiles`: (descriptors, count, pairs) of a subset of the rule book, default all of it"""
     desc, n_tiles = (tiles[0], tiles[1]) if tiles is not None else (m.tiles, m.n_tiles)
     call("lidog_sconv_gemm", ptr(A), ptr(gather), ptr(B), ptr(bias), ptr(desc[0]), ptr(desc[1]), ptr(desc[2]),
-         n_tiles, Cin, Cout, ptr(out), ptr(scatter))
+         n_tiles, Cin, Cout, ptr(out), ptr(scatter), A.shape[0])
 
 
 # row of the 5^3 neighbour table that holds offset k of the 3^3 kernel (both x fastest, centred)

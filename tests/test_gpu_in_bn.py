@@ -47,7 +47,7 @@ def test_gathered_gemm_and_weight_gradient_with_the_input_batchnorm_folded_in(Ci
     T1, T2 = torch.empty(m.P, Cout, device="cuda"), torch.empty(m.P, Cout, device="cuda")
     ME._gemm(y, m.pair_in, W, None, m, Cin, Cout, T1, None)
     call("lidog_sconv_gemm_in_bn", ptr(x), ptr(m.pair_in), ptr(W), None, ptr(m.tiles[0]), ptr(m.tiles[1]), ptr(m.tiles[2]),
-         m.n_tiles, Cin, Cout, ptr(T2), None, ptr(mean), ptr(invstd), ptr(w), ptr(b), 1)
+         m.n_tiles, Cin, Cout, ptr(T2), None, ptr(mean), ptr(invstd), ptr(w), ptr(b), 1, x.shape[0])
     assert torch.equal(T1, T2)
     # weight gradient
     items, n_items, item_off = ME._wgrad_items(m, Cin, Cout)
@@ -103,9 +103,9 @@ def test_the_folded_forms_refuse_what_they_cannot_do():
     v = torch.zeros(16, device="cuda")
     with pytest.raises(RuntimeError, match="matrix-core kernels only"):     # 16 input channels: no MFMA tile
         call("lidog_sconv_gemm_in_bn", ptr(x), ptr(m.pair_in), ptr(W), None, ptr(m.tiles[0]), ptr(m.tiles[1]),
-             ptr(m.tiles[2]), m.n_tiles, 16, 32, ptr(T), None, ptr(v), ptr(v), ptr(v), ptr(v), 1)
+             ptr(m.tiles[2]), m.n_tiles, 16, 32, ptr(T), None, ptr(v), ptr(v), ptr(v), ptr(v), 1, x.shape[0])
     x = torch.zeros(m.n_out, 32, device="cuda")
     W = torch.zeros(27, 32, 32, device="cuda")
     with pytest.raises(RuntimeError, match="vectors missing"):
         call("lidog_sconv_gemm_in_bn", ptr(x), ptr(m.pair_in), ptr(W), None, ptr(m.tiles[0]), ptr(m.tiles[1]),
-             ptr(m.tiles[2]), m.n_tiles, 32, 32, ptr(T), None, None, None, None, None, 1)
+             ptr(m.tiles[2]), m.n_tiles, 32, 32, ptr(T), None, None, None, None, None, 1, x.shape[0])
