@@ -37,12 +37,13 @@ PMC_TRAFFIC_FILE = f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_gemm_mfma.json"
 # allows the whole command 600 s, so the silence limit plus one safe-mode re-run must fit well inside that.  Every rank
 # reports its progress on stderr (beat() below) at least once per block of timed steps.
 WATCHDOG_DEFAULT_S = 150.0
+_T0 = time.time()
 
 
 def beat(msg):
     """one progress line on stderr -- what the silence watchdogs above this process (supervise_rank, launch_ranks)
     listen for; never on stdout, which carries rank 0's JSON line only"""
-    sys.stderr.write(f"bench.py[rank {os.environ.get('RANK', '0')}]: {msg}\n")
+    sys.stderr.write(f"bench.py[rank {os.environ.get('RANK', '0')} +{time.time() - _T0:.1f}s]: {msg}\n")
     sys.stderr.flush()
 
 
