@@ -429,15 +429,6 @@ __device__ __forceinline__ void os_epilogue(f32x16 (&acc)[NT], const float (&bv)
     }
 }
 
-#ifdef LIDOG_EXP_OS_SPLIT
-struct OsSplit {
-    int groups;
-    uint32_t mask[3];
-    int64_t slab;      // floats between the groups' output slabs (n * Cout)
-};
-static OsSplit g_os_split = {1, {0xFFFFFFFFu, 0, 0}, 0};
-#endif
-
 // MFMA 32x32x2 lane maps as in sconv_mfma.hip: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 // D[i][j]: j = l & 31, i = (e & 3) + 8 (e >> 2) + 4 (l >> 5).  MFMA column tile t of a wave = columns {li * NT + t}.
 // FOLD: the input rows are the raw output of the layer before; its BatchNorm + ReLU (InBn, sconv_mfma.h) is applied while
@@ -450,11 +441,7 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
                                                        const float *__restrict__ W, int reverse,
                                                        const float *__restrict__ bias,
                                                        const float *__restrict__ addend, int Cin, int Cout,
-                                                       float *__restrict__ out, OsStats st, InBn in_bn, int xcd_group
-#ifdef LIDOG_EXP_OS_SPLIT
-                                                       , OsSplit sp
-#endif
-) {
+                                                       float *__restrict__ out, OsStats st, InBn in_bn, int xcd_group) {
     constexpr int TN = 32 * NT;
     constexpr int BV = (OS_BK * TN / 4) / 256;
     __shared__ float As[OS_TM * OS_SA];
@@ -479,17 +466,8 @@ __global__ __launch_bounds__(256, MINW) void k_sconv_os_mfma(const float *__rest
     const int li = lane & 31, kh = lane >> 5;
     LIDOG_STAMP_BEGIN()
 
-#ifdef LIDOG_EXP_OS_SPLIT
-    // experiment: blockIdx.z = one of up to three ascending groups of offsets; the group's partial
-    // result goes to its own [n, Cout] slab, a second kernel adds the slabs in order
-    const uint32_t gmask = sp.groups > 1 ? sp.mask[blockIdx.z] : 0xFFFFFFFFu;
-    if (sp.groups > 1) out += (size_t)blockIdx.z * sp.slab;
-    const uint32_t wm = wave_masks[tile * 4 + wave] & gmask;
-    const uint32_t tm = (wave_masks[tile * 4] | wave_masks[tile * 4 + 1] | wave_masks[tile * 4 + 2] | wave_masks[tile * 4 + 3]) & gmask;
-#else
     const uint32_t wm = wave_masks[tile * 4 + wave];
     const uint32_t tm = wave_masks[tile * 4] | wave_masks[tile * 4 + 1] | wave_masks[tile * 4 + 2] | wave_masks[tile * 4 + 3];
-#endif
     if (tid < OS_TM) s_row[tid] = perm[(int64_t)tile * OS_TM + tid];
     __syncthreads();
     // neighbour table of the tile (one gather per (offset, row), all issued before use); offsets the tile does not
@@ -664,19 +642,13 @@ static int os_launch(const float *A, const int32_t *nbr, int64_t n, int K, const
     LIDOG_REQUIRE(A && nbr && perm && wave_masks && tile_order && W && out, "sconv_os: null argument");
     int nt = (Cout % 128 == 0) ? 4 : (Cout % 96 == 0) ? 3 : (Cout % 64 == 0) ? 2 : 1;
     dim3 grid((unsigned)(os_pad(n) / OS_TM), (unsigned)(Cout / (32 * nt)));
-#ifdef LIDOG_EXP_OS_SPLIT
-    grid.z = (unsigned)g_os_split.groups;
-#define OS_SPLIT_ARG , g_os_split
-#else
-#define OS_SPLIT_ARG
-#endif
     // runs of 4 consecutive tiles of the launch order per XCD (measured in the step, same box, alternating: 48.13 / 48.07 ->
     // 48.07 / 47.99 ms; 2: 48.11 / 47.95; 8: 48.14 / 48.20; 16: 48.23 / 48.35; 64: 50.3 -- the heaviest-first order must
     // survive)
     const int xcd_group = 4;
 #define OS_LAUNCHF(NT_, MW_, F_)                                                                                 \
     k_sconv_os_mfma<NT_, MW_, F_><<<grid, 256, 0, st>>>(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, \
-                                                        addend, Cin, Cout, out, stats, in_bn, xcd_group OS_SPLIT_ARG)
+                                                        addend, Cin, Cout, out, stats, in_bn, xcd_group)
 #define OS_LAUNCH(NT_, MW_) OS_LAUNCHF(NT_, MW_, false)
     if (in_bn.mean) {   // 16 more registers: the 64-column kernel no longer fits four waves per SIMD
         switch (nt) {
@@ -713,42 +685,6 @@ extern "C" int lidog_sconv_os(const float *A, const int32_t *nbr, int64_t n, int
     return os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, bias, addend, Cin, Cout, out, stats,
                      (hipStream_t)stream);
 }
-
-#ifdef LIDOG_EXP_OS_SPLIT
-__global__ __launch_bounds__(256) void k_exp_sum_slabs(const float4 *__restrict__ part, int64_t n4, int groups,
-                                                       float4 *__restrict__ out) {
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 a = part[i];
-        for (int g = 1; g < groups; ++g) {
-            const float4 b = part[(int64_t)g * n4 + i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-        out[i] = a;
-    }
-}
-// part [groups, n, Cout]: the partial sums over the offsets of masks[g] (ascending within a group); out = the slabs added
-// in order.  NOT the exact path's bits (another association of the per-offset additions).
-extern "C" int lidog_exp_sconv_os_split(const float *A, const int32_t *nbr, int64_t n, int32_t K, const int32_t *perm,
-                                        const uint32_t *wave_masks, const int32_t *tile_order, const float *W,
-                                        int32_t reverse, int32_t Cin, int32_t Cout, float *part, const uint32_t *masks,
-                                        int32_t groups, float *out, void *stream) {
-    if (n == 0) return 0;
-    LIDOG_REQUIRE(groups >= 1 && groups <= 3 && masks && part && out, "exp_sconv_os_split: bad arguments");
-    OsStats stats = {};
-    g_os_split.groups = groups;
-    for (int g = 0; g < 3; ++g) g_os_split.mask[g] = g < groups ? masks[g] : 0;
-    g_os_split.slab = n * (int64_t)Cout;
-    int rc = os_launch(A, nbr, n, K, perm, wave_masks, tile_order, W, reverse, nullptr, nullptr, Cin, Cout, part, stats,
-                       (hipStream_t)stream);
-    g_os_split = OsSplit{1, {0xFFFFFFFFu, 0, 0}, 0};
-    if (rc) return rc;
-    const int64_t n4 = n * Cout / 4;
-    k_exp_sum_slabs<<<(unsigned)(n4 / 256 / 4 + 1 > 2048 ? 2048 : n4 / 256 / 4 + 1), 256, 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const float4 *>(part), n4, groups, reinterpret_cast<float4 *>(out));
-    LIDOG_LAUNCH_CHECK();
-    return 0;
-}
-#endif
 
 // doubles of workspace of the two statistics forms: one partial row per 128-row tile + the group rows of the tail
 extern "C" int64_t lidog_sconv_os_stats_ws(int64_t n, int32_t C) {
