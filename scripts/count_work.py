@@ -1,7 +1,7 @@
 """Recomputes voxel counts N_s, rule-book sizes P and the algorithmic FLOPs / bytes per scan of the
 MinkUNet34(+BEV) forward from a synthetic scan (SURVEY.md 8(d) formulas), using the CPU oracle's maps.
 
-    python scripts/count_work.py [config] [seed]
+    python scripts/count_work.py [config] [seed] [mix3d]      (mix3d: the union of scans 2 seed and 2 seed + 1)
 FLOPs_l = 2 P_l Cin Cout;  bytes_l = 4 (N_in Cin + N_out Cout) + 4 K Cin Cout + 8 P_l;  BN(+ReLU) = 12 N C.
 """
 import os
@@ -20,7 +20,8 @@ from lidog_amd.minkunet import make_models  # noqa: E402
 def main():
     config = sys.argv[1] if len(sys.argv) > 1 else "kitti120k"
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    vox, _ = synth.scan_voxels(seed, config)
+    mix = len(sys.argv) > 3 and sys.argv[3] == "mix3d"
+    vox, _ = (synth.mix3d_voxels if mix else synth.scan_voxels)(seed, config)
     C = torch.from_numpy(np.concatenate([np.zeros((vox.shape[0], 1), np.int32), vox], axis=1))
     st = OME.SparseTensor(coordinates=C, features=torch.ones((C.shape[0], 1)))
     cm = st.coordinate_manager
