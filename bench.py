@@ -31,7 +31,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # f32-input MFMA peak = vector fp32 peak (MI355X_MICROARCH.md, Matrix cores)
 # scripts/profile_round.sh <tag> writes profiles/<tag>_pmc_traffic_sconv_gemm_mfma.json (FETCH_SIZE / WRITE_SIZE passes)
-PMC_TRAFFIC_TAG = "r05_f"
+PMC_TRAFFIC_TAG = "r06_f"
 PMC_TRAFFIC_FILE = f"{PMC_TRAFFIC_TAG}_pmc_traffic_sconv_gemm_mfma.json"
 # An N > 1 run that prints nothing for this long is taken to be hung (a collective that never completes): the driver
 # allows the whole command 600 s, so the silence limit plus one safe-mode re-run must fit well inside that.  Every rank
@@ -876,10 +876,11 @@ def main():
                                "traffic_source": f"profiles/{PMC_TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                                  f"over the {PMC_TRAFFIC_TAG} build (scripts/profile_round.sh), "
                                                  "not collected by this run" if traffic is not None else None,
-                               "kernel": "k_sconv_gemm_mfma (gathered GEMM of the sparse convolutions, f32 MFMA)",
+                               "kernel": "k_sconv_gemm_mfma / k_sconv_gemm_mfma_ms (gathered GEMM of the sparse convolutions, f32 MFMA)",
                                "note": "launch durations IN the step: since round 5 the forward launches share the chip with "
                                        "the downsample branches on the second stream and the backward ones with the weight "
-                                       "gradients (DESIGN.md 3a); one-stream durations: "
+                                       "gradients (DESIGN.md 3a); the in-kernel clock is 2.2-2.4 GHz (profiles/r06_clock_stamps.txt), "
+                                       "so the roof at the held clock is 144-157 TFLOP/s; one-stream durations: "
                                        f"profiles/{PMC_TRAFFIC_TAG}_kernel_stats_train_bs4_one_stream.csv",
                                "algorithmic_flops_per_launch": s["flops"] / s["launches"],
                                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
