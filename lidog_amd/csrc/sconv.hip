@@ -242,9 +242,11 @@ __global__ __launch_bounds__(256) void k_sconv_gemm_cin8(const float *__restrict
                                                          const int32_t *__restrict__ tile_k,
                                                          const int32_t *__restrict__ tile_row0,
                                                          const int32_t *__restrict__ tile_rows, int Cin, int Cout,
-                                                         float *__restrict__ T,
+                                                         float *T,
                                                          const int32_t *__restrict__ scatter,
-                                                         const float *__restrict__ addend) {
+                                                         const float *addend) {
+    // (T and addend are NOT restrict: the executor adds the classifier's data gradient onto the rows that already hold the
+    // BEV head's gradient in place, addend == T; every thread reads its float4 of the addend before it writes it)
     extern __shared__ float s_w[];  // [Cin][Cout]
     const int tile = blockIdx.x;
     const int k = tile_k[tile], row0 = tile_row0[tile], rows = tile_rows[tile];

@@ -406,6 +406,12 @@ extern "C" int lidog_trunk_forward(const int64_t *convs, const double *conv_f, i
         const int kind = (int)c[TC_KIND], Cin = (int)c[TC_CIN], Cout = (int)c[TC_COUT], K = (int)c[TC_K];
         const bool bn = op[TO_TYPE] == OP_CONVBN;
         const float *x = bp[op[TO_IN]];
+        // an input made by a side branch on the lane (in MinkUNet34 such a buffer is only ever read as a residual, below;
+        // a program that feeds it to a convolution is ordered here)
+        if (join_of[op[TO_IN]] && cur == stream && !ctx.dry) {
+            LIDOG_CHECK_HIP(hipStreamWaitEvent((hipStream_t)cur, join_of[op[TO_IN]], 0));
+            join_of[op[TO_IN]] = nullptr;
+        }
         const InBnArgs *in_bn = lazy[op[TO_IN]].pre ? &lazy[op[TO_IN]] : nullptr;   // 3^3 convolution + BatchNorm only
         const int64_t n = ctx.rows((int)op[TO_OUT]);
         const float *W = P<const float>(c[TC_W]), *bias = P<const float>(c[TC_BIAS]);
@@ -686,6 +692,9 @@ extern "C" int lidog_trunk_backward(const int64_t *convs, const double *conv_f, 
     const int n_buckets = buckets ? (int)dp.d[DP_N_BUCKETS] : 0;
     if ((lane || buckets) && !ctx.dry) {
         // [0, n_convs): lane forks; n_convs: the final join; then two per gradient bucket (main / lane -> bucket stream)
+        LIDOG_REQUIRE(n_convs + 1 + 2 * n_buckets < SIDE_EVENT0,
+                      "trunk: %d convolutions + %d gradient buckets need more events than the %d in front of the side streams' range",
+                      n_convs, n_buckets, (int)SIDE_EVENT0);
         events = event_pool(n_convs + 1 + 2 * n_buckets);
         LIDOG_REQUIRE(events, "trunk: cannot create events");
     }
