@@ -427,8 +427,9 @@ def supervise_rank():
     * and the supervisor exits NON-ZERO either way (124: the fallback printed its line; 125: it failed too), so a
       degraded figure can never pass for the real one.
 
-    A worker that EXITS (any code) is not a hang: the supervisor leaves with its code and the launcher ends the other
-    ranks.  SIGTERM / SIGINT (the launcher tearing the job down) end the worker's process group first.
+    A worker that exits non-zero gets the same single fallback attempt (the other ranks reach theirs through the silence
+    limit; the rendezvous of the fallback group waits for them).  SIGTERM / SIGINT (the launcher tearing the job down) end
+    the worker's process group first.
     LIDOG_BENCH_FALLBACK=0 skips the second run; LIDOG_BENCH_WORKER_SCRIPT replaces the worker (tests)."""
     import signal
     import subprocess
@@ -436,6 +437,7 @@ def supervise_rank():
     limit = float(os.environ.get("LIDOG_BENCH_WATCHDOG_S", str(WATCHDOG_DEFAULT_S)))
     script = os.environ.get("LIDOG_BENCH_WORKER_SCRIPT", os.path.abspath(__file__))
     current = [None]
+    reached_result = [False]
 
     def stop_child():
         p = current[0]
@@ -471,6 +473,8 @@ def supervise_rank():
         def pump():
             for line in p.stderr:
                 last[0] = time.time()
+                if "result line out" in line or "timed region done" in line:
+                    reached_result[0] = True       # the measurement is out: whatever happens later, no second line
                 sys.stderr.write(line)
                 sys.stderr.flush()
 
@@ -487,11 +491,21 @@ def supervise_rank():
             time.sleep(0.25)
 
     rc, silent = run_worker({}, False)
-    if not silent:
-        sys.exit(rc if rc >= 0 else 128 - rc)
-    beat(f"worker reported nothing for {limit:.0f} s and was killed")
-    if os.environ.get("LIDOG_BENCH_FALLBACK", "1") == "0":
-        sys.exit(124)
+    if not silent and rc == 0:
+        sys.exit(0)
+    fallback = os.environ.get("LIDOG_BENCH_FALLBACK", "1") != "0" and not reached_result[0]
+    if silent:
+        beat(f"worker reported nothing for {limit:.0f} s and was killed")
+        if not fallback:
+            sys.exit(124)
+    else:
+        # a worker that FAILED (a communicator that cannot be set up between these GPUs, a launch error): the other ranks'
+        # workers are then stuck in a collective and their supervisors arrive here through the silence limit; the safe mode
+        # takes none of this library's communicators, so it is worth one attempt.  The exit code stays non-zero either way.
+        code = rc if rc >= 0 else 128 - rc
+        beat(f"worker exited with code {code}")
+        if not fallback:
+            sys.exit(code)
     port = 20000 + (int(os.environ.get("MASTER_PORT", "29500")) + 7919) % 40000      # the same on every rank
     beat(f"starting the safe-mode fallback (LIDOG_DP_SAFE=1, rendezvous port {port})")
     rc, silent = run_worker(dict(LIDOG_DP_SAFE="1", LIDOG_BENCH_MODE="safe-fallback", MASTER_ADDR="127.0.0.1",

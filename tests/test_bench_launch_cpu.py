@@ -210,13 +210,23 @@ def test_a_fallback_that_hangs_too_ends_with_125_and_no_line(tmp_path):
     assert "went silent too" in p.stderr
 
 
-def test_a_worker_that_exits_is_not_a_hang(tmp_path):
-    p, dt = _supervise(tmp_path, """
+def test_a_worker_that_fails_gets_one_fallback_attempt_and_the_exit_code_stays_non_zero(tmp_path):
+    """a communicator that cannot be set up on the first multi-GPU box must not cost the line either"""
+    p, dt = _supervise(tmp_path, _WORKER % "sys.stderr.write('boom\\n'); sys.exit(7)", extra_env={"LIDOG_BENCH_WATCHDOG_S": "30"})
+    assert p.returncode == 124 and "boom" in p.stderr and "worker exited with code 7" in p.stderr and dt < 60
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["mode"] == "safe-fallback"
+    # without the fallback the worker's code is passed on
+    p, _ = _supervise(tmp_path, _WORKER % "sys.exit(7)", extra_env={"LIDOG_BENCH_FALLBACK": "0"})
+    assert p.returncode == 7 and not p.stdout.strip()
+    # a worker that fails AFTER its line is out (bench.py's peer_error exit) keeps that line the only one
+    p, _ = _supervise(tmp_path, """
         import sys
-        sys.stderr.write("boom\\n")
-        sys.exit(7)
-        """, extra_env={"LIDOG_BENCH_WATCHDOG_S": "3"})
-    assert p.returncode == 7 and "boom" in p.stderr and "safe-mode" not in p.stderr
+        print('{"peer_error": "x"}', flush=True)
+        sys.stderr.write("bench.py[rank 0 +1.0s]: result line out\\n"); sys.stderr.flush()
+        sys.exit(1)
+        """)
+    assert p.returncode == 1 and [l for l in p.stdout.splitlines() if l.startswith("{")] == ['{"peer_error": "x"}']
 
 
 def test_fallback_can_be_switched_off(tmp_path):
