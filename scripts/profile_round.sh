@@ -18,7 +18,7 @@ if [[ $what == *trace* ]]; then
     if [ $mode = one ]; then export LIDOG_BACKWARD_OVERLAP=0; else unset LIDOG_BACKWARD_OVERLAP; fi
     STEPS=$STEPS_TRACE rocprofv3 --kernel-trace --stats -d $d -o t -- python3 scripts/prof_train.py > gpurun_out/prof_${tag}_$mode.log 2>&1
     sfx=""; [ $mode = one ] && sfx="_one_stream"
-    python3 scripts/kernel_breakdown.py $d/t_results.db $STEPS_TRACE --csv $out/${tag}_kernel_stats_train_bs4$sfx.csv --top > $out/${tag}_kernel_breakdown_train_bs4$sfx.txt
+    python3 scripts/kernel_breakdown.py $d/t_results.db $STEPS_TRACE --csv $out/${tag}_kernel_stats_train_bs${BS:-4}$sfx.csv --top > $out/${tag}_kernel_breakdown_train_bs${BS:-4}$sfx.txt
     python3 scripts/step_timeline.py $d/t_results.db > $out/${tag}_step_timeline$sfx.txt 2>&1 || true
     rm -rf $d
   done
