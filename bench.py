@@ -845,7 +845,11 @@ def main():
                           "voxels_per_scan": n_vox, "seed0_stride_counts": seed0_counts,
                           "global_batch": world * args.batch,
                           "parallelism": f"dp{world}" + ("+syncbn" if world > 1 or single_dp else ""),
-                          "env": experiment_env()},
+                          "env": experiment_env(),
+                          # how the weight-gradient work items were cut (me._wgrad_chunk: 1 / 2 = whole rounds of the
+                          # kernel's resident workgroups, 0 = not; the default follows the stream mode, so one-stream and
+                          # two-stream runs differ in the last bits of the weight gradients unless LIDOG_WGRAD_FIT pins it)
+                          "wgrad_fit": ME._WGRAD_FIT if ME._WGRAD_FIT >= 0 else (0 if ME._WgradLane.enabled else 1)},
                "blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in blocks], "loss": loss,
                # "safe-fallback": the line of supervise_rank's second run after the first one went silent
                "mode": os.environ.get("LIDOG_BENCH_MODE", "normal")}
