@@ -367,7 +367,7 @@ def test_a_hung_two_rank_run_still_produces_a_fallback_line():
     import socket
     import subprocess
     env = dict(os.environ, LIDOG_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LIDOG_BENCH_FAULT="bucket_hang:1",
-               LIDOG_BENCH_WATCHDOG_S="20")
+               LIDOG_BENCH_WATCHDOG_S="40")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LIDOG_PEER_ALLREDUCE", "LIDOG_DP_SAFE"):
         env.pop(k, None)
     with socket.socket() as sk:
